@@ -1,0 +1,48 @@
+# Builds the MI355X-native render library and its checker.
+#   make            -> raytracers_amd/libray_mi355x.so  (HIP, gfx950) + tools
+#   make oracle     -> oracle/build/liboracle.so        (CPU oracle, test infrastructure)
+# -ffp-contract=off is load-bearing on both host and device: parity is bit-exact fp32.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := raytracers_amd/csrc
+OBJ     := build/obj
+LIB     := raytracers_amd/libray_mi355x.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter
+HOSTFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
+
+all: $(LIB) tools oracle
+
+$(OBJ)/render_kernels.o: $(CSRC)/render_kernels.hip $(CSRC)/lane_core.h $(CSRC)/rt_device.hpp
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/host_build.o: $(CSRC)/host_build.cpp $(CSRC)/rt_host.hpp
+	@mkdir -p $(OBJ)
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
+
+$(LIB): $(OBJ)/render_kernels.o $(OBJ)/api.o $(OBJ)/host_build.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+# native harness (our own bench front-end; the reference's futhark/main.c links the same way)
+build/rtbench: tools/rtbench.c include/ray.h include/rt_mi355x.h $(LIB)
+	@mkdir -p build
+	$(CC) -O2 -std=gnu99 -Wall -Iinclude -o $@ tools/rtbench.c -Lraytracers_amd -lray_mi355x -Wl,-rpath,'$$ORIGIN/../raytracers_amd' -lm
+
+build/wavesim: tools/wavesim.cpp $(CSRC)/lane_core.h $(CSRC)/rt_host.hpp $(OBJ)/host_build.o
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -fopenmp -I$(CSRC) -o $@ tools/wavesim.cpp $(OBJ)/host_build.o
+
+tools: build/rtbench
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all tools oracle clean

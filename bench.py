@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- the render hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one frame of EACH scene of the headline metric (BASELINE.json: "Mray/s
+(primary+secondary) on rgbbox & irreg 1000x1000"): render rgbbox 1000x1000, then irreg
+1000x1000, scene data (BVH, spheres, camera) already resident in HBM.  With N > 1 every
+frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total work fixed) and
+the framebuffer is gathered to rank 0 over RCCL inside the timed region.
+
+value = rays of all K steps / wall time (max over ranks), in Mray/s; a ray = one objs_hit
+call (futhark/ray.fut:130).  Ray and box/sphere-test counts come from an instrumented launch
+and are cross-checked against the oracle-derived constants below.
+
+The JSON line also carries
+  roofline      for the dominant kernel (the rgbbox launch of persistent_kernel): ALGORITHMIC
+                bytes per launch (32 B per box test + 16 B per sphere test + 4 B per pixel,
+                SURVEY.md 8d) / mean launch duration measured with events on the launch stream
+                inside the timed region, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (a port of the reference's Futhark program, OpenMP over rows)
+                timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+# (rays, box tests, sphere tests) per frame, from the CPU oracle (tests/test_oracle_golden.py
+# pins the oracle to the reference's golden images; SURVEY.md 8d lists the same numbers).
+FRAME_WORK = {
+    ("rgbbox", 1000, 1000): (4022099, 117685724, 25443619),
+    ("irreg", 1000, 1000): (1728608, 50741777, 9664717),
+    ("irreg", 4000, 4000): (27663974, 812246528, 154642404),
+}
+
+WORKLOADS = {
+    "rgbbox+irreg-1000": [("rgbbox", 1000, 1000), ("irreg", 1000, 1000)],
+    "rgbbox-1000": [("rgbbox", 1000, 1000)],
+    "irreg-1000": [("irreg", 1000, 1000)],
+    "irreg-4000": [("irreg", 4000, 4000)],
+    "big-2000": [("big", 2000, 2000)],
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def bytes_alg(box, sph, h, w):
+    return 32 * box + 16 * sph + 4 * h * w
+
+
+def cpu_baseline(frames, budget_s=12.0):
+    """Times the CPU oracle (tests/oracle_lib.py -> oracle/ray_oracle.c) on the same frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    scenes = [(O.OracleScene(s), h, w) for s, h, w in frames]
+    cores = int(O.lib().orc_num_threads())
+    rays = 0
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        for sc, h, w in scenes:
+            _, cnt = sc.render(h, w, threads=0)
+            rays += cnt["rays"]
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full frame(s) of each of {'+'.join(f'{s} {w}x{h}' for s, h, w in frames)}, "
+                      f"OpenMP dynamic over rows on all {cores} host threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 pixel kernel, 2 persistent kernel")
+    ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
+
+    frames = WORKLOADS[args.workload]
+    opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
+    renderers = []
+    for scene, h, w in frames:
+        pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=opts)
+        renderers.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
+
+    # work per frame: instrumented launch (rank 0 is enough), checked against the oracle table
+    work = {}
+    for scene, h, w, pr, _ in renderers:
+        st = pr.prepared.stats()
+        got = (st["rays"], st["box_tests"], st["leaf_tests"])
+        want = FRAME_WORK.get((scene, h, w))
+        if want is not None and got != want:
+            raise SystemExit(f"work counters of {scene} {w}x{h} differ from the oracle's: {got} vs {want}")
+        work[(scene, h, w)] = got
+
+    def step(events=None):
+        for i, (_, _, _, _, sr) in enumerate(renderers):
+            sr.render(events[i] if events is not None else None)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in renderers]
+          for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch kernel durations on this rank (events on the launch stream = torch's current stream)
+    kern_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
+               for i in range(len(renderers))]
+
+    if rank == 0:
+        rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
+        value = rays_step * args.steps / elapsed / 1e6
+        per_scene = {}
+        for i, (scene, h, w, _, _) in enumerate(renderers):
+            r, b, s = work[(scene, h, w)]
+            ba = bytes_alg(b, s, h, w) / world        # this rank's share of the frame (cyclic tiles)
+            per_scene[f"{scene}_{w}x{h}"] = {
+                "rays": r, "kernel_ms": kern_ms[i], "Mray_s_kernel": r / world / (kern_ms[i] * 1e-3) / 1e6,
+                "alg_bytes_per_launch": ba, "alg_GBs": ba / (kern_ms[i] * 1e-3) / 1e9}
+        dom = max(range(len(renderers)), key=lambda i: kern_ms[i])
+        dscene, dh, dw = frames[dom]
+        dkey = f"{dscene}_{dw}x{dh}"
+        achieved = per_scene[dkey]["alg_GBs"]
+        out = {
+            "metric": "Mray/s (primary+secondary) on rgbbox & irreg 1000x1000" if args.workload == "rgbbox+irreg-1000"
+                      else f"Mray/s (primary+secondary) on {args.workload}",
+            "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
+            "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
+                       "kernel": {0: "auto (persistent)", 1: "pixel", 2: "persistent"}[args.variant],
+                       "options": opts, "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": f"persistent_kernel on {dscene} {dw}x{dh}" if args.variant != 1
+                         else f"pixel_kernel on {dscene} {dw}x{dh}",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "achieved = algorithmic bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) / mean "
+                                 "launch time; the scene is LDS/L2 resident so real HBM traffic is ~4 B/pixel"},
+            "per_scene": per_scene,
+            "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
+                                  "note": "README.md:50 render times / oracle ray counts; different hardware"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

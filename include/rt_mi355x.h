@@ -1,0 +1,115 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X-native render hot path (libray_mi355x.so).
+ *
+ * This is the "internal" surface the Futhark-shaped drop-in boundary (include/ray.h)
+ * is built on.  It mirrors the reference's language-level call surface
+ *
+ *     render(objs, width, height, cam) -> [pixel]
+ *       futhark/ray.fut:166-169 (render_image), :241-247 (prepare_scene / render)
+ *       rust/src/lib.rs:430-444, haskell/Raytracing.hs:187-190
+ *
+ * with plain pointers and sizes only (no torch / HIP types in any signature; a HIP
+ * stream is passed as an opaque void*).  Every entry returns 0 on success and a
+ * non-zero code on failure; rt_last_error() gives the message (the reference's
+ * harness convention: `assert(ret == 0)`, futhark/main.c:74,97,116,131).
+ *
+ * All rendering entries ENQUEUE work on the context's stream and return; the
+ * completion point is rt_context_sync() (futhark_context_sync, main.c:98,117).
+ * There is no CPU fallback: without a usable HIP device context creation fails.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;    /* one device + one stream + work-queue state */
+typedef struct rt_scene rt_scene;        /* `scene` (ray.fut:171-174): spheres + look_from/look_at/fov, host */
+typedef struct rt_prepared rt_prepared;  /* `prepared_scene` (ray.fut:239): device-resident BVH + camera */
+
+/* Kernel families (rt_context_set_variant).  All produce bit-identical pixels. */
+enum {
+  RT_VARIANT_AUTO = 0,        /* best known configuration for the scene size */
+  RT_VARIANT_PIXEL = 1,       /* one thread per pixel, BVH in HBM/L2, no LDS staging (BASELINE configs[1]) */
+  RT_VARIANT_PERSISTENT = 2   /* persistent waves: work queue + in-place lane refill + phase voting,
+                                 top BVH levels staged in LDS (BASELINE configs[2]) */
+};
+
+/* ---- context ------------------------------------------------------------------ */
+/* device < 0: the current HIP device.  stream == NULL: the context creates and owns
+ * a stream; otherwise the caller's hipStream_t is used (e.g. torch's current stream). */
+int rt_context_create(rt_context **out, int device, void *hip_stream);
+void rt_context_destroy(rt_context *ctx);
+const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
+int rt_context_sync(rt_context *ctx);
+int rt_context_set_variant(rt_context *ctx, int variant);
+/* Tuning knobs by name (see DESIGN.md "knobs"); unknown name -> error. */
+int rt_context_set_option(rt_context *ctx, const char *name, int64_t value);
+int rt_context_device_info(const rt_context *ctx, int *device, int *num_cu, int *lds_bytes, char *name, int name_len);
+
+/* ---- scenes (ray.fut:176-237) -------------------------------------------------- */
+int rt_scene_rgbbox(rt_context *ctx, rt_scene **out);
+int rt_scene_irreg(rt_context *ctx, rt_scene **out);
+/* The irreg generator with its constants exposed: n x n spheres, extent k, y = 0.
+ * irreg == (100, 600); SURVEY 8(d) "big" == (1000, 6000). */
+int rt_scene_floor(rt_context *ctx, rt_scene **out, int n, float k);
+/* Arbitrary scene: spheres7 = n x {pos.xyz, colour.xyz, radius}. */
+int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7, int64_t n,
+                          const float look_from[3], const float look_at[3], float fov);
+int64_t rt_scene_num_spheres(const rt_scene *scene);
+int rt_scene_free(rt_context *ctx, rt_scene *scene);
+
+/* ---- prepare_scene (ray.fut:241-244): BVH build + camera, uploaded to the device - */
+int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, int64_t w, const rt_scene *scene);
+int rt_prepared_free(rt_context *ctx, rt_prepared *ps);
+int64_t rt_prepared_num_spheres(const rt_prepared *ps);
+/* Canonical `bvh = {L, I}` (bvh.fut:28) copied back from the device for parity checks.
+ * L7: n x 7 floats; bmin/bmax: (n-1) x 3; left/right: (n-1) encoded ptr (inner i -> i,
+ * leaf i -> -2 - i); parent: (n-1).  Any pointer may be NULL. */
+int rt_prepared_get_bvh(rt_context *ctx, const rt_prepared *ps, float *L7, float *bmin, float *bmax,
+                        int32_t *left, int32_t *right, int32_t *parent);
+int rt_prepared_get_camera(rt_context *ctx, const rt_prepared *ps, float cam12[12]);
+
+/* ---- render (ray.fut:246-247 -> render_image :166-169) -------------------------- */
+/* Whole image: out_dev = device pointer to h*w int32, row-major from the top row. */
+int rt_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t *out_dev);
+/* Row-tile partition for multi-GPU: the image is cut into tiles of rows_per_tile rows;
+ * part p of nparts renders tiles t with t % nparts == p, packed in tile order into
+ * out_dev (rt_part_rows(h, rows_per_tile, p, nparts) * w int32).  max_depth: the
+ * reference's bounce limit is 50 (ray.fut:154). */
+int rt_render_part(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                   int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev);
+/* The language-level surface itself: render_image objs width height cam (ray.fut:166) with an
+ * explicit camera (12 floats: origin, llc, horizontal, vertical; ray.fut:88-91) instead of the
+ * one prepare_scene derived.  cam12 == NULL: the prepared camera (then h, w must match it). */
+int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int64_t height, const float cam12[12],
+                    int32_t max_depth, int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev);
+int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);
+/* Scatter one part's packed rows into a full h*w image on the device (rank-0 side of
+ * the framebuffer gather). */
+int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t part, int32_t nparts,
+                  const int32_t *part_dev, int32_t *image_dev);
+
+/* Work counters of one frame, computed on the device by an instrumented launch of the
+ * same traversal: rays (objs_hit calls), box tests, sphere tests. */
+int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                    uint64_t stats3[3]);
+
+/* Times `iters` back-to-back launches of rt_render_part with HIP events recorded on the
+ * context's stream (after `warmup` untimed launches); ms_out[i] = duration of launch i. */
+int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                    int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev,
+                    int32_t warmup, int32_t iters, float *ms_out);
+
+/* ---- device buffers for hosts that have no allocator of their own (the C harness) -- */
+int rt_device_alloc(rt_context *ctx, void **out_dev, int64_t bytes);
+int rt_device_free(rt_context *ctx, void *dev);
+int rt_copy_to_host(rt_context *ctx, void *dst_host, const void *src_dev, int64_t bytes);  /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

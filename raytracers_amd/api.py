@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference's call surface for the render path,
+
+    scene   = rgbbox() | irreg()                       futhark/ray.fut:176, :223
+    prepared = prepare_scene(h, w, scene)              futhark/ray.fut:241-244
+    pixels  = render(h, w, prepared)                   futhark/ray.fut:246-247
+    pixels  = render_image(objs, width, height, cam)   futhark/ray.fut:166-169
+
+over the C ABI of libray_mi355x.so (include/rt_mi355x.h).  Pixels are the reference's packed
+i32 `(r<<16)|(g<<8)|b`, row-major from the top row.  Every render launches HIP kernels on the
+context's stream; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+
+VARIANT_AUTO, VARIANT_PIXEL, VARIANT_PERSISTENT = 0, 1, 2
+MAX_DEPTH = 50          # ray.fut:154
+ROWS_PER_TILE = 8       # cyclic row-tile height of the multi-GPU partition
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Context:
+    """One HIP device + one stream.  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that launches order with torch work."""
+
+    def __init__(self, device=-1, stream=None):
+        h = C.c_void_p()
+        rc = lib.rt_context_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0 or not h.value:
+            raise RtError(f"rt_context_create failed (code {rc}): no usable HIP device; "
+                          "raytracers_amd has no CPU fallback")
+        self._h = h
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(lib.rt_last_error(self._h).decode() or f"error code {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rt_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(lib.rt_context_sync(self._h))
+
+    def set_variant(self, v):
+        self._check(lib.rt_context_set_variant(self._h, int(v)))
+
+    def set_option(self, name, value):
+        self._check(lib.rt_context_set_option(self._h, name.encode(), int(value)))
+
+    def device_info(self):
+        dev, cus, lds = C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(64)
+        self._check(lib.rt_context_device_info(self._h, C.byref(dev), C.byref(cus), C.byref(lds), name, 64))
+        return {"device": dev.value, "num_cu": cus.value, "lds_bytes": lds.value, "arch": name.value.decode()}
+
+    # -- scenes
+    def _scene(self, fn, *args):
+        h = C.c_void_p()
+        self._check(fn(self._h, C.byref(h), *args))
+        return Scene(self, h)
+
+    def rgbbox(self):
+        return self._scene(lib.rt_scene_rgbbox)
+
+    def irreg(self):
+        return self._scene(lib.rt_scene_irreg)
+
+    def floor(self, n, k):
+        return self._scene(lib.rt_scene_floor, int(n), float(k))
+
+    def scene(self, name):
+        if name == "rgbbox":
+            return self.rgbbox()
+        if name == "irreg":
+            return self.irreg()
+        if name == "big":
+            return self.floor(1000, 6000.0)
+        raise ValueError(f"unknown scene {name!r}")
+
+    def scene_from_spheres(self, spheres7, look_from, look_at, fov):
+        s = np.ascontiguousarray(spheres7, dtype=np.float32)
+        if s.ndim != 2 or s.shape[1] != 7:
+            raise ValueError("spheres7 must be (n, 7): pos.xyz, colour.rgb, radius")
+        lf = (C.c_float * 3)(*look_from)
+        la = (C.c_float * 3)(*look_at)
+        h = C.c_void_p()
+        self._check(lib.rt_scene_from_spheres(self._h, C.byref(h), s.ctypes.data, s.shape[0], lf, la, float(fov)))
+        return Scene(self, h)
+
+    # -- device memory for callers without an allocator of their own
+    def alloc_i32(self, count):
+        return DeviceBuffer(self, int(count) * 4)
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._check(lib.rt_device_alloc(ctx._h, C.byref(p), nbytes))
+        self.ptr = p.value
+
+    def to_host(self, shape):
+        out = np.empty(shape, dtype=np.int32)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(lib.rt_copy_to_host(self.ctx._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx._h:
+            lib.rt_device_free(self.ctx._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Scene:
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    @property
+    def num_spheres(self):
+        return int(lib.rt_scene_num_spheres(self._h))
+
+    def free(self):
+        if self._h and self.ctx._h:
+            lib.rt_scene_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Prepared:
+    """prepared_scene = {objs: bvh, cam: camera} (ray.fut:239), resident on the device."""
+
+    def __init__(self, ctx, h, height, width):
+        self.ctx, self._h, self.h, self.w = ctx, h, int(height), int(width)
+
+    @property
+    def num_spheres(self):
+        return int(lib.rt_prepared_num_spheres(self._h))
+
+    def camera(self):
+        cam = np.empty(12, dtype=np.float32)
+        self.ctx._check(lib.rt_prepared_get_camera(self.ctx._h, self._h, cam.ctypes.data))
+        return cam
+
+    def bvh_arrays(self):
+        """Canonical {L, I} of bvh.fut:28 copied back from the device (for parity checks)."""
+        n = self.num_spheres
+        ni = n - 1
+        A = {"L": np.empty((n, 7), np.float32), "bmin": np.empty((ni, 3), np.float32),
+             "bmax": np.empty((ni, 3), np.float32), "left": np.empty(ni, np.int32),
+             "right": np.empty(ni, np.int32), "parent": np.empty(ni, np.int32)}
+        self.ctx._check(lib.rt_prepared_get_bvh(self.ctx._h, self._h, *[A[k].ctypes.data for k in
+                                                                       ("L", "bmin", "bmax", "left", "right", "parent")]))
+        return A
+
+    def stats(self, max_depth=MAX_DEPTH):
+        s = (C.c_uint64 * 3)()
+        self.ctx._check(lib.rt_render_stats(self.ctx._h, self._h, self.h, self.w, int(max_depth), s))
+        return {"rays": int(s[0]), "box_tests": int(s[1]), "leaf_tests": int(s[2])}
+
+    def free(self):
+        if self._h and self.ctx._h:
+            lib.rt_prepared_free(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def prepare_scene(h, w, scene):
+    """entry prepare_scene h w scene (ray.fut:241): BVH build + camera for an h x w image."""
+    ctx = scene.ctx
+    p = C.c_void_p()
+    ctx._check(lib.rt_prepare_scene(ctx._h, C.byref(p), int(h), int(w), scene._h))
+    return Prepared(ctx, p, h, w)
+
+
+def part_rows(h, part=0, nparts=1, rows_per_tile=ROWS_PER_TILE):
+    return int(lib.rt_part_rows(int(h), int(rows_per_tile), int(part), int(nparts)))
+
+
+def render_into(out_ptr, h, w, prepared, max_depth=MAX_DEPTH, part=0, nparts=1, rows_per_tile=ROWS_PER_TILE, cam=None):
+    """Enqueue a render of part `part` of `nparts` into the device pointer `out_ptr`
+    (part_rows(h, part, nparts) * w int32).  Asynchronous: ctx.sync() completes it."""
+    ctx = prepared.ctx
+    if cam is None:
+        ctx._check(lib.rt_render_part(ctx._h, prepared._h, int(h), int(w), int(max_depth), int(rows_per_tile),
+                                      int(part), int(nparts), C.c_void_p(out_ptr)))
+    else:
+        c = np.ascontiguousarray(cam, dtype=np.float32)
+        assert c.size == 12
+        ctx._check(lib.rt_render_image(ctx._h, prepared._h, int(w), int(h), c.ctypes.data, int(max_depth),
+                                       int(rows_per_tile), int(part), int(nparts), C.c_void_p(out_ptr)))
+
+
+def render(h, w, prepared, max_depth=MAX_DEPTH):
+    """entry render h w prepared (ray.fut:246): returns the [h][w]i32 image as a numpy array."""
+    buf = prepared.ctx.alloc_i32(h * w)
+    try:
+        render_into(buf.ptr, h, w, prepared, max_depth)
+        return buf.to_host((h, w))
+    finally:
+        buf.free()
+
+
+def render_image(objs, width, height, cam, max_depth=MAX_DEPTH):
+    """render_image objs width height cam (ray.fut:166): explicit camera (12 floats)."""
+    buf = objs.ctx.alloc_i32(height * width)
+    try:
+        render_into(buf.ptr, height, width, objs, max_depth, cam=cam)
+        return buf.to_host((height, width))
+    finally:
+        buf.free()
+
+
+def render_timed(out_ptr, h, w, prepared, warmup, iters, max_depth=MAX_DEPTH, part=0, nparts=1,
+                 rows_per_tile=ROWS_PER_TILE):
+    """`iters` back-to-back launches timed with HIP events on the context's stream; returns ms per launch."""
+    ctx = prepared.ctx
+    ms = np.zeros(iters, dtype=np.float32)
+    ctx._check(lib.rt_render_timed(ctx._h, prepared._h, int(h), int(w), int(max_depth), int(rows_per_tile), int(part),
+                                   int(nparts), C.c_void_p(out_ptr), int(warmup), int(iters), ms.ctypes.data))
+    return ms
+
+
+def place_part(ctx, h, w, part, nparts, part_ptr, image_ptr, rows_per_tile=ROWS_PER_TILE):
+    ctx._check(lib.rt_place_part(ctx._h, int(h), int(w), int(rows_per_tile), int(part), int(nparts),
+                                 C.c_void_p(part_ptr), C.c_void_p(image_ptr)))

@@ -1,0 +1,620 @@
+// api.cpp -- the C ABI of libray_mi355x.so: the rt_* surface (include/rt_mi355x.h) and,
+// on top of it, the Futhark-shaped drop-in boundary (include/ray.h) that the reference's
+// futhark/main.c is written against.
+//
+// There is no CPU fallback anywhere in this library: every render entry launches HIP
+// kernels, and context creation fails loudly when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ray.h"
+#include "../../include/rt_mi355x.h"
+#include "rt_device.hpp"
+#include "rt_host.hpp"
+
+// ------------------------------------------------------------------------------------
+struct rt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int num_cu = 0;
+  int lds_bytes = 0;
+  std::string name;
+  // configuration
+  int variant = RT_VARIANT_AUTO;
+  int waves_per_wg = 8;     // persistent family: waves per workgroup (4, 8, 16)
+  int wgs_per_cu = 2;       // persistent workgroups per CU
+  int thr_shade = 24;       // phase vote: lanes wanting the shade phase that trigger it
+  int thr_leaf = 24;        // phase vote: lanes holding deferred leaves that trigger the sphere phase
+  int lmax = 8;             // deferred-leaf capacity per lane
+  int lds_scene_bytes = -1; // < 0: as much as fits
+  int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  // ticket counter of the persistent family: monotonic across launches, never reset.
+  // A launch with C chunks and W waves performs exactly C + W atomic increments (every
+  // wave stops at its first out-of-range ticket), so the next launch's base is known.
+  unsigned *queue_dev = nullptr;
+  unsigned queue_base = 0;
+  unsigned long long *stats_dev = nullptr;
+};
+
+struct rt_scene {
+  rt::SceneDesc desc;
+};
+
+struct rt_prepared {
+  int64_t n = 0;
+  int64_t h = 0, w = 0;
+  rt::Camera cam{};
+  int height = 0;   // tree height
+  // canonical {L, I} on the device (SoA, as bvh.fut:28 lays them out)
+  float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
+  int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
+  // traversal copy
+  float4 *nodes = nullptr, *sph = nullptr, *col = nullptr;
+};
+
+namespace {
+
+int fail(rt_context *ctx, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return 1;
+}
+int hip_fail(rt_context *ctx, hipError_t e, const char *what) {
+  return fail(ctx, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RT_HIP(ctx, call)                                        \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) return hip_fail((ctx), e_, #call);     \
+  } while (0)
+
+template <class T>
+int upload(rt_context *ctx, T **dev, const void *host, size_t bytes) {
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(dev), std::max<size_t>(bytes, 16)));
+  RT_HIP(ctx, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+struct Plan {
+  int variant;
+  int lds_nodes, lds_sph, smax, lmax, waves, grid;
+  size_t lds_bytes;
+};
+
+// Decide the launch shape of the persistent family for one prepared scene.
+int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
+  pl->variant = ctx->variant == RT_VARIANT_AUTO ? RT_VARIANT_PERSISTENT : ctx->variant;
+  if (pl->variant == RT_VARIANT_PIXEL) return 0;
+  const int ni = static_cast<int>(ps->n - 1), n = static_cast<int>(ps->n);
+  // depth-first with one node held in a register: at most one pending sibling per level
+  const int need = ps->height + 1;
+  int smax = 64;
+  for (int cand : {12, 16, 20, 24, 32, 48, 64})
+    if (cand >= need) { smax = cand; break; }
+  if (need > 64) return fail(ctx, "BVH deeper than 64 levels: unsupported by the persistent kernel");
+  pl->smax = smax;
+  pl->lmax = ctx->lmax;
+  pl->waves = ctx->waves_per_wg;
+  const int total = std::min(ctx->lds_bytes, 160 * 1024) / std::max(1, ctx->wgs_per_cu);
+  const int scratch = pl->waves * (pl->smax + pl->lmax) * 64 * 4;
+  int budget = total - scratch - 512;
+  if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
+  if (budget < 0) return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
+  int ln, ls;
+  if (ctx->lds_sph_first) {
+    ls = std::min(n, budget / 16);
+    ln = std::min(ni, (budget - ls * 16) / 32);
+  } else {
+    ln = std::min(ni, budget / 32);
+    ls = std::min(n, (budget - ln * 32) / 16);
+  }
+  pl->lds_nodes = ln;
+  pl->lds_sph = ls;
+  pl->lds_bytes = rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
+  pl->grid = ctx->num_cu * ctx->wgs_per_cu;
+  return 0;
+}
+
+int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                   int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr) {
+  if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
+  if (!out_dev) return fail(ctx, "null output pointer");
+  if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30))
+    return fail(ctx, "image size out of range");
+  if (!cam12 && (h != ps->h || w != ps->w))
+    return fail(ctx, "render size differs from the size the scene was prepared for (the camera aspect is fixed by prepare_scene)");
+  if (rows_per_tile <= 0 || nparts <= 0 || part < 0 || part >= nparts) return fail(ctx, "bad row-tile partition");
+  if (max_depth < 0) return fail(ctx, "negative max_depth");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  rtk::KParams p{};
+  p.nodes = ps->nodes; p.sph = ps->sph; p.col = ps->col;
+  std::memcpy(&p.cam, cam12 ? static_cast<const void *>(cam12) : static_cast<const void *>(&ps->cam), sizeof(p.cam));
+  p.w = static_cast<int>(w); p.h = static_cast<int>(h);
+  p.rows_local = static_cast<int>(rt::part_rows(h, rows_per_tile, part, nparts));
+  p.rows_per_tile = rows_per_tile; p.part = part; p.nparts = nparts;
+  p.tiles_x = (p.w + 7) / 8;
+  p.max_depth = max_depth;
+  p.out = out_dev;
+  p.stats = ctx->stats_dev;
+  if (p.rows_local == 0) return 0;
+  if (max_depth == 0) {
+    // `while depth < 0`: no ray is traced, every pixel is the initial colour (0,0,0)
+    RT_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * static_cast<size_t>(p.rows_local) * p.w, ctx->stream));
+    return 0;
+  }
+  Plan pl{};
+  if (stats) pl.variant = RT_VARIANT_PIXEL;
+  else if (int rc = make_plan(ctx, ps, &pl)) return rc;
+  if (pl.variant == RT_VARIANT_PIXEL) {
+    RT_HIP(ctx, rtk::launch_pixel(p, stats, ctx->stream));
+    return 0;
+  }
+  p.queue = ctx->queue_dev;
+  p.queue_base = ctx->queue_base;
+  p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
+  p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
+  p.smax = pl.smax; p.lmax = pl.lmax;
+  p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
+  RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
+  ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ context
+extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream) {
+  if (!out) return 1;
+  *out = nullptr;
+  auto ctx = std::make_unique<rt_context>();
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    std::fprintf(stderr, "libray_mi355x: no usable HIP device (%s); this library has no CPU path\n",
+                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return 2;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= count) return 3;
+  if (hipSetDevice(device) != hipSuccess) return 4;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 5;
+  ctx->num_cu = prop.multiProcessorCount;
+  ctx->lds_bytes = static_cast<int>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+                                                                           : prop.sharedMemPerBlock);
+  ctx->name = prop.gcnArchName;
+  if (hip_stream) {
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return 6;
+    ctx->own_stream = true;
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->queue_dev), 256) != hipSuccess) return 7;
+  if (hipMemset(ctx->queue_dev, 0, 256) != hipSuccess) return 7;
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return 7;
+  if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return 7;
+  if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
+  *out = ctx.release();
+  return 0;
+}
+
+extern "C" void rt_context_destroy(rt_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
+  if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int rt_context_sync(rt_context *ctx) {
+  if (!ctx) return 1;
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
+  if (!ctx) return 1;
+  if (variant < RT_VARIANT_AUTO || variant > RT_VARIANT_PERSISTENT) return fail(ctx, "unknown variant");
+  ctx->variant = variant;
+  return 0;
+}
+
+extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return 1;
+  const std::string k(name);
+  const int v = static_cast<int>(value);
+  if (k == "waves_per_wg") {
+    if (v != 4 && v != 8 && v != 16) return fail(ctx, "waves_per_wg must be 4, 8 or 16");
+    ctx->waves_per_wg = v;
+  } else if (k == "wgs_per_cu") {
+    if (v < 1 || v > 8) return fail(ctx, "wgs_per_cu must be 1..8");
+    ctx->wgs_per_cu = v;
+  } else if (k == "thr_shade") {
+    ctx->thr_shade = std::max(1, std::min(64, v));
+  } else if (k == "thr_leaf") {
+    ctx->thr_leaf = std::max(1, std::min(64, v));
+  } else if (k == "lmax") {
+    if (v < 2 || v > 32) return fail(ctx, "lmax must be 2..32");
+    ctx->lmax = v;
+  } else if (k == "lds_scene_bytes") {
+    ctx->lds_scene_bytes = v;
+  } else if (k == "lds_sph_first") {
+    ctx->lds_sph_first = v != 0;
+  } else {
+    return fail(ctx, "unknown option: " + k);
+  }
+  return 0;
+}
+
+extern "C" int rt_context_device_info(const rt_context *ctx, int *device, int *num_cu, int *lds_bytes, char *name,
+                                      int name_len) {
+  if (!ctx) return 1;
+  if (device) *device = ctx->device;
+  if (num_cu) *num_cu = ctx->num_cu;
+  if (lds_bytes) *lds_bytes = ctx->lds_bytes;
+  if (name && name_len > 0) {
+    std::strncpy(name, ctx->name.c_str(), static_cast<size_t>(name_len) - 1);
+    name[name_len - 1] = 0;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ scenes
+static int new_scene(rt_context *ctx, rt_scene **out, rt::SceneDesc &&d) {
+  if (!ctx || !out) return fail(ctx, "null argument");
+  *out = new rt_scene{std::move(d)};
+  return 0;
+}
+extern "C" int rt_scene_rgbbox(rt_context *ctx, rt_scene **out) { return new_scene(ctx, out, rt::make_rgbbox()); }
+extern "C" int rt_scene_irreg(rt_context *ctx, rt_scene **out) { return new_scene(ctx, out, rt::make_floor(100, 600.0f)); }
+extern "C" int rt_scene_floor(rt_context *ctx, rt_scene **out, int n, float k) {
+  if (n < 2 || n > 4096) return fail(ctx, "floor scene: n out of range (2..4096)");
+  return new_scene(ctx, out, rt::make_floor(n, k));
+}
+extern "C" int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7, int64_t n,
+                                     const float look_from[3], const float look_at[3], float fov) {
+  if (!spheres7 || !look_from || !look_at) return fail(ctx, "null argument");
+  if (n < 2 || n > (int64_t(1) << 27)) return fail(ctx, "scene needs 2 .. 2^27 spheres");
+  rt::SceneDesc d;
+  d.spheres.resize(static_cast<size_t>(n));
+  std::memcpy(d.spheres.data(), spheres7, sizeof(rt::Sphere) * static_cast<size_t>(n));
+  std::copy(look_from, look_from + 3, d.look_from);
+  std::copy(look_at, look_at + 3, d.look_at);
+  d.fov = fov;
+  return new_scene(ctx, out, std::move(d));
+}
+extern "C" int64_t rt_scene_num_spheres(const rt_scene *scene) {
+  return scene ? static_cast<int64_t>(scene->desc.spheres.size()) : 0;
+}
+extern "C" int rt_scene_free(rt_context *, rt_scene *scene) {
+  delete scene;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ prepare_scene
+extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, int64_t w, const rt_scene *scene) {
+  if (!ctx || !out || !scene) return fail(ctx, "null argument");
+  if (h <= 0 || w <= 0) return fail(ctx, "image size must be positive");
+  if (scene->desc.spheres.size() < 2) return fail(ctx, "scene needs at least 2 spheres");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
+  const rt::TravLayout tl = rt::make_trav_layout(bvh);
+  auto ps = std::make_unique<rt_prepared>();
+  ps->n = bvh.n;
+  ps->h = h; ps->w = w;
+  ps->cam = rt::scene_camera(scene->desc, h, w);
+  ps->height = tl.height;
+  const size_t n = static_cast<size_t>(bvh.n), ni = n - 1;
+  int rc = 0;
+  rc |= upload(ctx, &ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
+  rc |= upload(ctx, &ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
+  rc |= upload(ctx, &ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
+  rc |= upload(ctx, &ps->left, bvh.left.data(), ni * sizeof(int32_t));
+  rc |= upload(ctx, &ps->right, bvh.right.data(), ni * sizeof(int32_t));
+  rc |= upload(ctx, &ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
+  rc |= upload(ctx, &ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
+  rc |= upload(ctx, &ps->sph, tl.sph.data(), n * 16);
+  rc |= upload(ctx, &ps->col, tl.col.data(), n * 16);
+  // the host staging vectors die at scope exit: drain the copies first
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (rc || e != hipSuccess) {
+    rt_prepared_free(ctx, ps.release());
+    return rc ? rc : hip_fail(ctx, e, "hipStreamSynchronize");
+  }
+  *out = ps.release();
+  return 0;
+}
+
+extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
+  if (!ps) return 0;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  for (void *p : {static_cast<void *>(ps->L7), static_cast<void *>(ps->bmin), static_cast<void *>(ps->bmax),
+                  static_cast<void *>(ps->left), static_cast<void *>(ps->right), static_cast<void *>(ps->parent),
+                  static_cast<void *>(ps->nodes), static_cast<void *>(ps->sph), static_cast<void *>(ps->col)})
+    if (p) (void)hipFree(p);
+  delete ps;
+  return 0;
+}
+
+extern "C" int64_t rt_prepared_num_spheres(const rt_prepared *ps) { return ps ? ps->n : 0; }
+
+extern "C" int rt_prepared_get_bvh(rt_context *ctx, const rt_prepared *ps, float *L7, float *bmin, float *bmax,
+                                   int32_t *left, int32_t *right, int32_t *parent) {
+  if (!ctx || !ps) return fail(ctx, "null argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t n = static_cast<size_t>(ps->n), ni = n - 1;
+  if (L7) RT_HIP(ctx, hipMemcpy(L7, ps->L7, n * 28, hipMemcpyDeviceToHost));
+  if (bmin) RT_HIP(ctx, hipMemcpy(bmin, ps->bmin, ni * 12, hipMemcpyDeviceToHost));
+  if (bmax) RT_HIP(ctx, hipMemcpy(bmax, ps->bmax, ni * 12, hipMemcpyDeviceToHost));
+  if (left) RT_HIP(ctx, hipMemcpy(left, ps->left, ni * 4, hipMemcpyDeviceToHost));
+  if (right) RT_HIP(ctx, hipMemcpy(right, ps->right, ni * 4, hipMemcpyDeviceToHost));
+  if (parent) RT_HIP(ctx, hipMemcpy(parent, ps->parent, ni * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int rt_prepared_get_camera(rt_context *ctx, const rt_prepared *ps, float cam12[12]) {
+  if (!ctx || !ps || !cam12) return fail(ctx, "null argument");
+  std::memcpy(cam12, &ps->cam, sizeof(rt::Camera));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ render
+extern "C" int rt_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t *out_dev) {
+  return enqueue_render(ctx, ps, h, w, 50, 8, 0, 1, out_dev, false);
+}
+
+extern "C" int rt_render_part(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                              int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev) {
+  return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false);
+}
+
+extern "C" int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int64_t height, const float cam12[12],
+                               int32_t max_depth, int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev) {
+  return enqueue_render(ctx, objs, height, width, max_depth, rows_per_tile, part, nparts, out_dev, false, cam12);
+}
+
+extern "C" int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts) {
+  return rt::part_rows(h, rows_per_tile, part, nparts);
+}
+
+extern "C" int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t part, int32_t nparts,
+                             const int32_t *part_dev, int32_t *image_dev) {
+  if (!ctx || !part_dev || !image_dev) return fail(ctx, "null argument");
+  if (rows_per_tile <= 0 || nparts <= 0 || part < 0 || part >= nparts) return fail(ctx, "bad row-tile partition");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const int rows_local = static_cast<int>(rt::part_rows(h, rows_per_tile, part, nparts));
+  RT_HIP(ctx, rtk::launch_place_part(part_dev, image_dev, static_cast<int>(w), rows_local, rows_per_tile, part, nparts,
+                                     ctx->stream));
+  return 0;
+}
+
+extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                               uint64_t stats3[3]) {
+  if (!ctx || !ps || !stats3) return fail(ctx, "null argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t *tmp = nullptr;
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(int32_t) * static_cast<size_t>(h) * w));
+  RT_HIP(ctx, hipMemsetAsync(ctx->stats_dev, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  int rc = enqueue_render(ctx, ps, h, w, max_depth, 8, 0, 1, tmp, true);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  unsigned long long host[3] = {0, 0, 0};
+  if (!rc && e == hipSuccess) e = hipMemcpy(host, ctx->stats_dev, sizeof host, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(ctx, e, "rt_render_stats");
+  for (int i = 0; i < 3; ++i) stats3[i] = host[i];
+  return 0;
+}
+
+extern "C" int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                               int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev, int32_t warmup,
+                               int32_t iters, float *ms_out) {
+  if (!ctx || !ms_out || iters <= 0 || warmup < 0) return fail(ctx, "bad argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < warmup; ++i)
+    if (int rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false)) return rc;
+  std::vector<hipEvent_t> ev(static_cast<size_t>(iters) + 1);
+  for (auto &e : ev) RT_HIP(ctx, hipEventCreate(&e));
+  RT_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; ++i) {
+    rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false);
+    if (!rc && hipEventRecord(ev[i + 1], ctx->stream) != hipSuccess) rc = fail(ctx, "hipEventRecord failed");
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (!rc && e == hipSuccess)
+    for (int i = 0; i < iters; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(ctx, e, "rt_render_timed");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ buffers
+extern "C" int rt_device_alloc(rt_context *ctx, void **out_dev, int64_t bytes) {
+  if (!ctx || !out_dev || bytes < 0) return fail(ctx, "bad argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMalloc(out_dev, std::max<int64_t>(bytes, 16)));
+  return 0;
+}
+extern "C" int rt_device_free(rt_context *ctx, void *dev) {
+  if (!ctx) return 1;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipFree(dev));
+  return 0;
+}
+extern "C" int rt_copy_to_host(rt_context *ctx, void *dst_host, const void *src_dev, int64_t bytes) {
+  if (!ctx || !dst_host || !src_dev || bytes < 0) return fail(ctx, "bad argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ====================================================================================
+// The Futhark-shaped boundary (include/ray.h) -- thin wrappers over the rt_* surface.
+// ====================================================================================
+struct futhark_context_config {
+  int device = -1;
+  int debugging = 0, logging = 0, profiling = 0;
+};
+struct futhark_context {
+  rt_context *rt = nullptr;
+  std::string pending;   // error not yet collected by futhark_context_get_error
+  int logging = 0;
+  uint64_t renders = 0, prepares = 0;
+};
+struct futhark_opaque_scene {
+  rt_scene *s = nullptr;
+};
+struct futhark_opaque_prepared_scene {
+  rt_prepared *p = nullptr;
+};
+struct futhark_i32_2d {
+  int32_t *dev = nullptr;
+  int64_t shape[2] = {0, 0};
+};
+
+namespace {
+int fut_fail(futhark_context *ctx, int rc) {
+  if (rc && ctx) ctx->pending = rt_last_error(ctx->rt);
+  return rc;
+}
+}  // namespace
+
+extern "C" struct futhark_context_config *futhark_context_config_new(void) { return new futhark_context_config(); }
+extern "C" void futhark_context_config_free(struct futhark_context_config *cfg) { delete cfg; }
+extern "C" void futhark_context_config_set_debugging(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->debugging = flag; }
+extern "C" void futhark_context_config_set_logging(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->logging = flag; }
+extern "C" void futhark_context_config_set_profiling(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->profiling = flag; }
+extern "C" void futhark_context_config_set_device(struct futhark_context_config *cfg, const char *s) {
+  if (!cfg || !s) return;
+  if (*s == '#') ++s;
+  cfg->device = std::atoi(s);
+}
+
+extern "C" struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) {
+  auto ctx = std::make_unique<futhark_context>();
+  ctx->logging = cfg ? (cfg->logging | cfg->debugging) : 0;
+  const int rc = rt_context_create(&ctx->rt, cfg ? cfg->device : -1, nullptr);
+  if (rc) {
+    // Futhark returns a context whose error is set; main.c asserts it is NULL.
+    ctx->pending = "libray_mi355x: cannot create a HIP context (code " + std::to_string(rc) + "); no CPU path exists";
+  }
+  return ctx.release();
+}
+extern "C" void futhark_context_free(struct futhark_context *ctx) {
+  if (!ctx) return;
+  rt_context_destroy(ctx->rt);
+  delete ctx;
+}
+extern "C" char *futhark_context_get_error(struct futhark_context *ctx) {
+  if (!ctx || ctx->pending.empty()) return nullptr;
+  char *s = static_cast<char *>(std::malloc(ctx->pending.size() + 1));
+  if (s) std::memcpy(s, ctx->pending.c_str(), ctx->pending.size() + 1);
+  ctx->pending.clear();
+  return s;
+}
+extern "C" int futhark_context_sync(struct futhark_context *ctx) {
+  if (!ctx || !ctx->rt) return 1;
+  return fut_fail(ctx, rt_context_sync(ctx->rt));
+}
+extern "C" char *futhark_context_report(struct futhark_context *ctx) {
+  char buf[512];
+  int dev = -1, cus = 0, lds = 0;
+  char name[64] = "";
+  if (ctx && ctx->rt) rt_context_device_info(ctx->rt, &dev, &cus, &lds, name, sizeof name);
+  std::snprintf(buf, sizeof buf, "libray_mi355x: device %d (%s), %d CUs, %d B LDS/CU; %llu prepare_scene, %llu render calls\n",
+                dev, name, cus, lds, ctx ? (unsigned long long)ctx->prepares : 0ull,
+                ctx ? (unsigned long long)ctx->renders : 0ull);
+  char *s = static_cast<char *>(std::malloc(std::strlen(buf) + 1));
+  if (s) std::strcpy(s, buf);
+  return s;
+}
+
+extern "C" int futhark_entry_rgbbox(struct futhark_context *ctx, struct futhark_opaque_scene **out0) {
+  if (!ctx || !ctx->rt || !out0) return 1;
+  auto o = std::make_unique<futhark_opaque_scene>();
+  if (int rc = rt_scene_rgbbox(ctx->rt, &o->s)) return fut_fail(ctx, rc);
+  *out0 = o.release();
+  return 0;
+}
+extern "C" int futhark_entry_irreg(struct futhark_context *ctx, struct futhark_opaque_scene **out0) {
+  if (!ctx || !ctx->rt || !out0) return 1;
+  auto o = std::make_unique<futhark_opaque_scene>();
+  if (int rc = rt_scene_irreg(ctx->rt, &o->s)) return fut_fail(ctx, rc);
+  *out0 = o.release();
+  return 0;
+}
+extern "C" int futhark_entry_prepare_scene(struct futhark_context *ctx, struct futhark_opaque_prepared_scene **out0,
+                                           const int64_t in0, const int64_t in1, const struct futhark_opaque_scene *in2) {
+  if (!ctx || !ctx->rt || !out0 || !in2) return 1;
+  auto o = std::make_unique<futhark_opaque_prepared_scene>();
+  if (int rc = rt_prepare_scene(ctx->rt, &o->p, in0, in1, in2->s)) return fut_fail(ctx, rc);
+  ctx->prepares++;
+  *out0 = o.release();
+  return 0;
+}
+extern "C" int futhark_entry_render(struct futhark_context *ctx, struct futhark_i32_2d **out0, const int64_t in0,
+                                    const int64_t in1, const struct futhark_opaque_prepared_scene *in2) {
+  if (!ctx || !ctx->rt || !out0 || !in2) return 1;
+  auto img = std::make_unique<futhark_i32_2d>();
+  void *dev = nullptr;
+  if (int rc = rt_device_alloc(ctx->rt, &dev, static_cast<int64_t>(sizeof(int32_t)) * in0 * in1)) return fut_fail(ctx, rc);
+  img->dev = static_cast<int32_t *>(dev);
+  img->shape[0] = in0;
+  img->shape[1] = in1;
+  if (int rc = rt_render(ctx->rt, in2->p, in0, in1, img->dev)) {
+    rt_device_free(ctx->rt, dev);
+    return fut_fail(ctx, rc);
+  }
+  ctx->renders++;
+  *out0 = img.release();
+  return 0;
+}
+extern "C" int futhark_values_i32_2d(struct futhark_context *ctx, struct futhark_i32_2d *arr, int32_t *data) {
+  if (!ctx || !ctx->rt || !arr || !data) return 1;
+  return fut_fail(ctx, rt_copy_to_host(ctx->rt, data, arr->dev, static_cast<int64_t>(sizeof(int32_t)) * arr->shape[0] * arr->shape[1]));
+}
+extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i32_2d *arr) {
+  if (!arr) return 0;
+  int rc = 0;
+  if (ctx && ctx->rt && arr->dev) rc = rt_device_free(ctx->rt, arr->dev);
+  delete arr;
+  return fut_fail(ctx, rc);
+}
+extern "C" const int64_t *futhark_shape_i32_2d(struct futhark_context *, struct futhark_i32_2d *arr) {
+  return arr ? arr->shape : nullptr;
+}
+extern "C" int futhark_free_opaque_prepared_scene(struct futhark_context *ctx, struct futhark_opaque_prepared_scene *obj) {
+  if (!obj) return 0;
+  if (ctx && ctx->rt) rt_prepared_free(ctx->rt, obj->p);
+  delete obj;
+  return 0;
+}
+extern "C" int futhark_free_opaque_scene(struct futhark_context *ctx, struct futhark_opaque_scene *obj) {
+  if (!obj) return 0;
+  rt_scene_free(ctx ? ctx->rt : nullptr, obj->s);
+  delete obj;
+  return 0;
+}

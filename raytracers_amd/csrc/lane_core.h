@@ -1,0 +1,189 @@
+// lane_core.h -- per-lane arithmetic of the render hot path, shared by every kernel
+// family (render_kernels.hip) and by the host-side wave simulator (tools/wavesim.cpp,
+// a design tool that executes the same per-lane code with 64 emulated lanes).
+//
+// Parity contract: IEEE binary32, no FMA contraction (build with
+// -ffp-contract=off), correctly rounded / and sqrt, fmaxf/fminf NaN semantics, and the
+// reference's operation order.  Each function cites the Futhark lines it follows.
+//
+// What is NOT taken from the reference is the traversal ORDER.  bvh_fold
+// (futhark/bvh.fut:61-84) walks parent pointers and meets leaves in increasing index
+// order; here a leaf is tested iff every ancestor box passes aabb_hit with the FIXED
+// interval (0, 1e9) (ray.fut:77 closes over the outer t_max), and the winner is the
+// smallest accepted root, ties to the lowest leaf index -- the same (j, t) the fold
+// returns, for any visiting order.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtk {
+
+constexpr float kTMax = 1000000000.0f;   // ray.fut:130
+constexpr float kEps = 0.1f;             // scene_epsilon, ray.fut:3
+constexpr float kNoHit = __builtin_inff();
+
+struct Cam {   // camera (ray.fut:88-91) as 12 floats
+  float ox, oy, oz, lx, ly, lz, hx, hy, hz, vx, vy, vz;
+};
+
+struct Ray {
+  float ox, oy, oz;
+  float dx, dy, dz;
+  float ix, iy, iz;   // 1/d per axis: aabb_hit's invD (ray.fut:55) depends on the ray only
+  float a;            // dot d d: sphere_hit's `a` (ray.fut:34) and norm's argument (prim.fut:26)
+};
+
+RT_HD float dot3(float ax, float ay, float az, float bx, float by, float bz) {   // prim.fut:22-24
+  float px = ax * bx, py = ay * by, pz = az * bz;
+  return (px + py) + pz;
+}
+
+RT_HD void ray_derive(Ray &r) {
+  r.ix = 1.0f / r.dx;
+  r.iy = 1.0f / r.dy;
+  r.iz = 1.0f / r.dz;
+  r.a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+}
+
+// trace_ray + get_ray (ray.fut:150-154, :109-114).  `col` = i, `row` = image row from
+// the top; the reference evaluates pixel (j = row) at v = (height - j) / height.
+RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
+  const float u = (float)col / (float)width;
+  const float v = (float)(height - row) / (float)height;
+  Ray r;
+  r.ox = c.ox; r.oy = c.oy; r.oz = c.oz;
+  r.dx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
+  r.dy = ((c.ly + u * c.hy) + v * c.vy) - c.oy;
+  r.dz = ((c.lz + u * c.hz) + v * c.vz) - c.oz;
+  ray_derive(r);
+  return r;
+}
+
+// aabb_hit (ray.fut:53-70) with tmin0 = 0, tmax0 = 1e9.  The reference exits early after
+// the x and y slabs; evaluating all three and AND-ing the verdicts is the same predicate.
+RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  float tmin = 0.0f, tmax = kTMax;
+  bool ok;
+  {
+    const float t0 = (lox - r.ox) * r.ix, t1 = (hix - r.ox) * r.ix;
+    const bool neg = r.ix < 0.0f;
+    tmin = fmaxf(neg ? t1 : t0, tmin);
+    tmax = fminf(neg ? t0 : t1, tmax);
+    ok = !(tmax <= tmin);
+  }
+  {
+    const float t0 = (loy - r.oy) * r.iy, t1 = (hiy - r.oy) * r.iy;
+    const bool neg = r.iy < 0.0f;
+    tmin = fmaxf(neg ? t1 : t0, tmin);
+    tmax = fminf(neg ? t0 : t1, tmax);
+    ok = ok & !(tmax <= tmin);
+  }
+  {
+    const float t0 = (loz - r.oz) * r.iz, t1 = (hiz - r.oz) * r.iz;
+    const bool neg = r.iz < 0.0f;
+    tmin = fmaxf(neg ? t1 : t0, tmin);
+    tmax = fminf(neg ? t0 : t1, tmax);
+    ok = ok & !(tmax <= tmin);
+  }
+  return ok;
+}
+
+// The root closest_hit would accept for this sphere if its running t_max were large
+// (ray.fut:32-51 called with t_min = 0.1, :79): root1 if root1 > 0.1, else root2 if
+// root2 > 0.1, else none.  (root2 >= root1, so "root1 >= t_max, try root2" can never
+// succeed; the caller's `g < best` test is then exactly the reference's `temp < t_max`.)
+RT_HD float sphere_root(const Ray &r, float px, float py, float pz, float rad) {
+  const float ocx = r.ox - px, ocy = r.oy - py, ocz = r.oz - pz;
+  const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
+  const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rad * rad;
+  const float disc = b * b - r.a * c;
+  if (disc <= 0.0f) return kNoHit;
+  const float sq = sqrtf(disc);
+  float t = (-b - sq) / r.a;
+  if (!(t > kEps)) {
+    t = (-b + sq) / r.a;
+    if (!(t > kEps)) return kNoHit;
+  }
+  return t;
+}
+
+// closest_hit's accumulator update (ray.fut:78-81) made order-independent.
+RT_HD void closest_update(float g, int idx, float &best, int &bestj) {
+  if (g < best || (g == best && idx < bestj)) {
+    best = g;
+    bestj = idx;
+  }
+}
+
+RT_HD int32_t pack_pixel(float r, float g, float b) {   // colour_to_pixel, ray.fut:158-162
+  const int32_t ir = (int32_t)(255.99f * r);
+  const int32_t ig = (int32_t)(255.99f * g);
+  const int32_t ib = (int32_t)(255.99f * b);
+  return (ir << 16) | (ig << 8) | ib;
+}
+
+// One iteration of ray_colour's loop body AFTER the fold (ray.fut:126-148, :83-86,
+// :119-124): re-intersect the winning sphere with (0.0, best+1), scatter or terminate.
+// Returns true when the pixel continues with the scattered ray (r, light, depth updated);
+// false when the pixel is finished and *pixel holds its packed colour.
+//   sph = {pos.xyz, radius}, col = colour of sphere bestj (ignored when bestj < 0).
+RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float spz, float srad,
+                      float scr, float scg, float scb, float &lr, float &lg, float &lb, int &depth,
+                      int max_depth, int32_t *pixel) {
+  bool have = false;
+  float t = 0.0f;
+  if (bestj >= 0) {
+    // sphere_hit s r 0.0 (t_max+1): may pick the OTHER root than the fold did, or none.
+    const float ocx = r.ox - spx, ocy = r.oy - spy, ocz = r.oz - spz;
+    const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
+    const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - srad * srad;
+    const float disc = b * b - r.a * c;
+    if (!(disc <= 0.0f)) {
+      const float sq = sqrtf(disc);
+      const float lim = best + 1.0f;
+      t = (-b - sq) / r.a;
+      have = (t < lim) && (t > 0.0f);
+      if (!have) {
+        t = (-b + sq) / r.a;
+        have = (t < lim) && (t > 0.0f);
+      }
+    }
+  }
+  const float inv_norm = 1.0f / sqrtf(r.a);   // normalise r.dir = scale (1/norm d) d
+  if (have) {
+    // hit record (ray.fut:40-46)
+    const float hpx = r.ox + t * r.dx, hpy = r.oy + t * r.dy, hpz = r.oz + t * r.dz;
+    const float inv_rad = 1.0f / srad;
+    const float nx = inv_rad * (hpx - spx), ny = inv_rad * (hpy - spy), nz = inv_rad * (hpz - spz);
+    // scatter (ray.fut:119-124), reflect (ray.fut:116-117)
+    const float ux = inv_norm * r.dx, uy = inv_norm * r.dy, uz = inv_norm * r.dz;
+    const float k = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
+    const float rx = ux - k * nx, ry = uy - k * ny, rz = uz - k * nz;
+    if (dot3(rx, ry, rz, nx, ny, nz) > 0.0f && depth + 1 < max_depth) {
+      r.ox = hpx; r.oy = hpy; r.oz = hpz;
+      r.dx = rx; r.dy = ry; r.dz = rz;
+      ray_derive(r);
+      lr = lr * scr; lg = lg * scg; lb = lb * scb;
+      depth = depth + 1;
+      return true;
+    }
+    // absorbed, or the bounce budget is spent: colour = light * (0,0,0)
+    *pixel = pack_pixel(lr * 0.0f, lg * 0.0f, lb * 0.0f);
+    return false;
+  }
+  // miss: sky gradient (ray.fut:140-148)
+  const float uy = inv_norm * r.dy;
+  const float tt = 0.5f * (uy + 1.0f);
+  const float w = 1.0f - tt;
+  const float sr = w * 1.0f + tt * 0.5f, sg = w * 1.0f + tt * 0.7f, sb = w * 1.0f + tt * 1.0f;
+  *pixel = pack_pixel(lr * sr, lg * sg, lb * sb);
+  return false;
+}
+
+}  // namespace rtk

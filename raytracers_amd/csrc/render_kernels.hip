@@ -1,0 +1,310 @@
+// render_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the render hot
+// path: render_image / trace_ray / ray_colour / objs_hit / bvh_fold
+// (futhark/ray.fut:126-169, :76-86; futhark/bvh.fut:61-84).
+//
+// Two kernel families, bit-identical output:
+//   pixel_kernel       one thread per pixel, 8x8 pixel tile per wave, BVH read from
+//                      HBM/L2 (no LDS staging of the scene)          -> BASELINE configs[1]
+//   persistent_kernel  persistent waves pulling 8x8 tiles from a global ticket counter,
+//                      finished lanes refilled in place (ballot + mbcnt prefix), per-wave
+//                      phase voting {box, sphere, shade}, breadth-first BVH prefix and
+//                      sphere table staged in LDS, traversal stack + deferred-leaf list
+//                      in LDS                                        -> BASELINE configs[2]
+//
+// No MFMA: there is no dense contraction on this path.  Build: -ffp-contract=off and
+// the default correctly rounded fp32 divide/sqrt (parity is bit-exact).
+#include <hip/hip_runtime.h>
+
+#include "lane_core.h"
+#include "rt_device.hpp"
+
+namespace rtk {
+
+__device__ __forceinline__ int f2i(float f) { return __float_as_int(f); }
+
+// local (packed) row of this part -> row of the full image, cyclic row tiles
+__device__ __forceinline__ int global_row(const KParams &p, int lrow) {
+  const int k = lrow / p.rows_per_tile;
+  return (k * p.nparts + p.part) * p.rows_per_tile + (lrow - k * p.rows_per_tile);
+}
+
+// ---------------------------------------------------------------------------------
+// Family 1: one thread per pixel.
+// ---------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
+  // Traversal stack: [entry][lane] so a wave's accesses to one entry hit 64 distinct
+  // dwords.  Depth bound: a Karras tree over 32-bit keys + 32-bit index tie-break has
+  // height <= 64, and depth-first order keeps at most one pending sibling per level.
+  __shared__ int stack[kStackPixel][64];
+  const int lane = threadIdx.x;
+  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+  const int col = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
+  if (col >= p.w || lrow >= p.rows_local) return;
+  Ray r = primary_ray(p.cam, col, global_row(p, lrow), p.w, p.h);
+  float lr = 1.0f, lg = 1.0f, lb = 1.0f;
+  int depth = 0;
+  int32_t pixel = 0;
+  unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
+  for (;;) {
+    float best = kTMax;
+    int bestj = -1;
+    int sp = 0;
+    stack[sp++][lane] = 0;
+    if (STATS) n_rays++;
+    while (sp > 0) {
+      const int ni = stack[--sp][lane];
+      const float4 lo = p.nodes[2 * ni], hi = p.nodes[2 * ni + 1];
+      if (STATS) n_box++;
+      if (!box_hit(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) continue;
+      const int kids[2] = {f2i(lo.w), f2i(hi.w)};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = kids[k];
+        if (c < 0) {
+          const int j = ~c;
+          const float4 s = p.sph[j];
+          if (STATS) n_sph++;
+          closest_update(sphere_root(r, s.x, s.y, s.z, s.w), j, best, bestj);
+        } else {
+          stack[sp++][lane] = c;
+        }
+      }
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bestj >= 0) {
+      s = p.sph[bestj];
+      c = p.col[bestj];
+    }
+    if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) break;
+  }
+  p.out[(size_t)lrow * p.w + col] = pixel;
+  if (STATS) {
+    atomicAdd(&p.stats[0], n_rays);
+    atomicAdd(&p.stats[1], n_box);
+    atomicAdd(&p.stats[2], n_sph);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Family 2: persistent waves.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_rank(unsigned long long m) {   // # set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <int THREADS, bool STATS>
+__global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
+  const int SMAX = p.smax, LMAX = p.lmax;
+  extern __shared__ float4 smem[];
+  float4 *const lnodes = smem;                          // [2 * lds_nodes]  breadth-first BVH prefix
+  float4 *const lsph = smem + 2 * p.lds_nodes;          // [lds_sph]        {pos, radius}
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // per-wave scratch: stack[SMAX][64] then leaves[LMAX][64]; entry-major so that one
+  // entry of all 64 lanes is 64 consecutive dwords (bank = lane, conflict-free)
+  int *const wstack = reinterpret_cast<int *>(lsph + p.lds_sph) + wave * ((SMAX + LMAX) * 64) + lane;
+  int *const wleaf = wstack + SMAX * 64;
+
+  for (int i = threadIdx.x; i < 2 * p.lds_nodes; i += THREADS) lnodes[i] = p.nodes[i];
+  for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) lsph[i] = p.sph[i];
+  __syncthreads();
+
+  // ---- lane state ----
+  Ray r = {};
+  float lr = 1.0f, lg = 1.0f, lb = 1.0f;
+  int depth = 0;
+  int pix = -1;          // local pixel offset (lrow * w + col), or -1: no pixel
+  float best = kTMax;
+  int bestj = -1;
+  int cur = -1;          // inner node held in a register (or -1)
+  int sp = 0, nl = 0;    // stack / deferred-leaf counts
+  unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
+  // ---- wave state (uniform) ----
+  unsigned q_next = 0, q_end = 0;
+  bool exhausted = false;
+
+  for (;;) {
+    const bool has_node = (cur >= 0) | (sp > 0);
+    const bool can_box = has_node & (nl <= LMAX - 2);
+    const bool can_leaf = nl > 0;
+    const bool idle = !has_node & (nl == 0);
+    const bool want_shade = idle & ((pix >= 0) | !exhausted);
+    const unsigned long long mb = __ballot(can_box), ml = __ballot(can_leaf), ms = __ballot(want_shade);
+    if ((mb | ml | ms) == 0ull) break;
+    const int nb = __popcll(mb), nlv = __popcll(ml), ns = __popcll(ms);
+
+    int op;   // 0 box, 1 leaf, 2 shade  (wave-uniform)
+    if (ns >= p.thr_shade || (nb == 0 && nlv == 0)) op = 2;
+    else if (nlv >= p.thr_leaf || nb == 0) op = 1;
+    else op = 0;
+
+    if (op == 0) {
+      // ---- BOX: one inner node per lane ----
+      if (can_box) {
+        int ni = cur;
+        if (ni < 0) ni = wstack[(--sp) * 64];
+        float4 lo, hi;
+        if (ni < p.lds_nodes) {
+          lo = lnodes[2 * ni];
+          hi = lnodes[2 * ni + 1];
+        } else {
+          lo = p.nodes[2 * ni];
+          hi = p.nodes[2 * ni + 1];
+        }
+        if (STATS) n_box++;
+        int next = -1;
+        if (box_hit(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) {
+          const int cl = f2i(lo.w), cr = f2i(hi.w);
+          if (cl < 0) wleaf[(nl++) * 64] = ~cl; else next = cl;
+          if (cr < 0) wleaf[(nl++) * 64] = ~cr;
+          else if (next < 0) next = cr;
+          else wstack[(sp++) * 64] = cr;
+        }
+        cur = next;
+      }
+    } else if (op == 1) {
+      // ---- LEAF: one deferred sphere test per lane ----
+      if (can_leaf) {
+        const int j = wleaf[(--nl) * 64];
+        const float4 s = (j < p.lds_sph) ? lsph[j] : p.sph[j];
+        if (STATS) n_sph++;
+        closest_update(sphere_root(r, s.x, s.y, s.z, s.w), j, best, bestj);
+      }
+    } else {
+      // ---- SHADE: finish rays, then refill empty lanes from the tile queue ----
+      if (idle & (pix >= 0)) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bestj >= 0) {
+          s = (bestj < p.lds_sph) ? lsph[bestj] : p.sph[bestj];
+          c = p.col[bestj];
+        }
+        int32_t pixel;
+        if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          cur = 0;
+          best = kTMax;
+          bestj = -1;
+          if (STATS) n_rays++;
+        } else {
+          p.out[pix] = pixel;
+          pix = -1;
+        }
+      }
+      bool want = idle & (pix < 0) & !exhausted;
+      int slot = -1;                 // tile-queue slot assigned to this lane
+      unsigned long long m = __ballot(want);
+      while (m != 0ull) {            // wave-uniform loop
+        if (q_next == q_end) {
+          unsigned t = 0;
+          if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
+          t = __builtin_amdgcn_readfirstlane(t);
+          if (t >= (unsigned)p.nchunks) {
+            exhausted = true;
+            break;
+          }
+          q_next = t * 64u;
+          q_end = q_next + 64u;
+        }
+        const unsigned avail = q_end - q_next;
+        const unsigned rank = (unsigned)lane_rank(m);
+        const unsigned cnt = (unsigned)__popcll(m);
+        if (want & (rank < avail)) {
+          const unsigned sidx = q_next + rank;
+          const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
+          const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+          const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+          if (col < p.w && lrow < p.rows_local) {
+            slot = lrow * p.w + col;
+            want = false;
+          }
+        }
+        q_next += (cnt < avail) ? cnt : avail;
+        m = __ballot(want);
+      }
+      if (slot >= 0) {
+        const int lrow = slot / p.w, col = slot - lrow * p.w;
+        r = primary_ray(p.cam, col, global_row(p, lrow), p.w, p.h);
+        lr = 1.0f; lg = 1.0f; lb = 1.0f;
+        depth = 0;
+        pix = slot;
+        cur = 0;
+        best = kTMax;
+        bestj = -1;
+        if (STATS) n_rays++;
+      }
+    }
+  }
+  if (STATS) {
+    atomicAdd(&p.stats[0], n_rays);
+    atomicAdd(&p.stats[1], n_box);
+    atomicAdd(&p.stats[2], n_sph);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Framebuffer assembly: scatter one part's packed rows into the full image.
+// ---------------------------------------------------------------------------------
+__global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile,
+                                  int part_id, int nparts) {
+  const size_t total = (size_t)rows_local * w;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int lrow = (int)(i / w), col = (int)(i - (size_t)lrow * w);
+    const int k = lrow / rows_per_tile;
+    const int row = (k * nparts + part_id) * rows_per_tile + (lrow - k * rows_per_tile);
+    image[(size_t)row * w + col] = part[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Host-side launchers
+// ---------------------------------------------------------------------------------
+hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream) {
+  const int tiles_y = (p.rows_local + 7) / 8;
+  const unsigned grid = (unsigned)(p.tiles_x * tiles_y);
+  if (grid == 0) return hipSuccess;
+  if (stats) hipLaunchKernelGGL(pixel_kernel<true>, dim3(grid), dim3(64), 0, stream, p);
+  else hipLaunchKernelGGL(pixel_kernel<false>, dim3(grid), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg) {
+  return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (smax + lmax) * 64 * sizeof(int);
+}
+
+template <int THREADS, bool STATS>
+static hipError_t launch_persistent_t(const KParams &p, int grid, hipStream_t stream) {
+  const size_t lds = persistent_lds_bytes(p.lds_nodes, p.lds_sph, p.smax, p.lmax, THREADS / 64);
+  auto kfn = persistent_kernel<THREADS, STATS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
+  if (grid <= 0) return hipSuccess;
+  if (stats) return launch_persistent_t<512, true>(p, grid, stream);
+  switch (waves_per_wg) {
+  case 4: return launch_persistent_t<256, false>(p, grid, stream);
+  case 8: return launch_persistent_t<512, false>(p, grid, stream);
+  case 16: return launch_persistent_t<1024, false>(p, grid, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
+                             int nparts, hipStream_t stream) {
+  const size_t total = (size_t)rows_local * w;
+  if (total == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(place_part_kernel, dim3(grid), dim3(256), 0, stream, part, image, w, rows_local, rows_per_tile,
+                     part_id, nparts);
+  return hipGetLastError();
+}
+
+}  // namespace rtk

@@ -1,0 +1,43 @@
+// rt_device.hpp -- kernel parameter block and launcher declarations (host <-> .hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lane_core.h"
+
+namespace rtk {
+
+constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>= any LBVH height)
+
+struct KParams {
+  // scene (traversal copy; see rt::TravLayout)
+  const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
+  const float4 *sph;     // [n] {pos.xyz, radius}
+  const float4 *col;     // [n] {colour.rgb, 0}
+  Cam cam;
+  // image + partition
+  int w, h;              // full image
+  int rows_local;        // rows of this part (packed)
+  int rows_per_tile, part, nparts;
+  int tiles_x;           // ceil(w / 8)
+  int max_depth;
+  int32_t *out;          // [rows_local * w]
+  unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
+  // persistent family
+  unsigned *queue;       // monotonic ticket counter (never reset; see Context::queue_base)
+  unsigned queue_base;   // counter value at which this launch's ticket 0 sits
+  int nchunks;           // 8x8 tiles in this part
+  int lds_nodes;         // breadth-first node prefix staged in LDS
+  int lds_sph;           // sphere prefix staged in LDS
+  int smax, lmax;        // per-lane LDS stack / deferred-leaf capacities
+  int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
+};
+
+hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream);
+// block = 64 * waves_per_wg threads (4, 8 or 16 waves); grid = persistent workgroups
+hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
+size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg);
+hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
+                             int nparts, hipStream_t stream);
+
+}  // namespace rtk

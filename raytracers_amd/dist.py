@@ -1,0 +1,106 @@
+"""Multi-GPU rendering: cyclic row-tile partition + framebuffer gather.
+
+Pixels are independent (tabulate_2d, futhark/ray.fut:169), so the path shards by image
+rows with NO data-path collective; the only exchange is the final framebuffer gather to
+rank 0 (RCCL over xGMI when the backend is "nccl").  The partition is cyclic over tiles of
+ROWS_PER_TILE rows -- contiguous bands would give irreg's 8 ranks 0.1 % ... 25 % of the
+work each.  The BVH and camera are replicated: every rank builds them from
+the same scene description.
+
+One process per GPU (torch.distributed); the renderer of a part is injected so that the
+sharding/gather logic is testable on CPU with the gloo backend.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+def tile_rows(h, part, nparts, rows_per_tile=api.ROWS_PER_TILE):
+    """Image rows owned by `part`, in the packed order rt_render_part writes them."""
+    ntiles = (h + rows_per_tile - 1) // rows_per_tile
+    rows = [np.arange(t * rows_per_tile, min(h, (t + 1) * rows_per_tile)) for t in range(part, ntiles, nparts)]
+    return np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+
+
+def max_part_rows(h, nparts, rows_per_tile=api.ROWS_PER_TILE):
+    return max(len(tile_rows(h, p, nparts, rows_per_tile)) for p in range(nparts))
+
+
+class HipPartRenderer:
+    """Renders this rank's rows with the HIP library into a torch int32 CUDA tensor, on
+    torch's current stream (so torch.distributed collectives order after the kernel)."""
+
+    def __init__(self, scene_name, h, w, device, max_depth=api.MAX_DEPTH, variant=api.VARIANT_AUTO, options=None):
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = api.Context(self.device.index, stream)
+        self.ctx.set_variant(variant)
+        for k, v in (options or {}).items():
+            self.ctx.set_option(k, v)
+        self.scene = self.ctx.scene(scene_name)
+        self.prepared = api.prepare_scene(h, w, self.scene)
+        self.h, self.w, self.max_depth = h, w, max_depth
+
+    def __call__(self, part, nparts, out=None):
+        rows = api.part_rows(self.h, part, nparts)
+        if out is None:
+            out = torch.empty((rows, self.w), dtype=torch.int32, device=self.device)
+        assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.numel() >= rows * self.w
+        api.render_into(out.data_ptr(), self.h, self.w, self.prepared, self.max_depth, part, nparts)
+        return out
+
+    def place(self, part, nparts, part_tensor, image):
+        api.place_part(self.ctx, self.h, self.w, part, nparts, part_tensor.data_ptr(), image.data_ptr())
+
+
+class ShardedRenderer:
+    """render(h, w) across the ranks of a torch.distributed group: each rank renders its
+    cyclic row tiles, rank `dst` gathers and assembles the [h][w]i32 image.
+
+    part_renderer(part, nparts, out) must fill out[:part_rows] (out: [pad_rows, w] int32 on
+    `device`) and may be asynchronous on the device's current stream."""
+
+    def __init__(self, part_renderer, h, w, device, group=None, dst=0):
+        self.render_part = part_renderer
+        self.h, self.w, self.group, self.dst = h, w, group, dst
+        self.device = torch.device(device)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pad_rows = max_part_rows(h, self.world)
+        self.send = torch.zeros((self.pad_rows, w), dtype=torch.int32, device=self.device)
+        self.recv = None
+        self.image = None
+        if self.rank == dst:
+            self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
+            self.image = torch.empty((h, w), dtype=torch.int32, device=self.device)
+
+    def render(self, events=None):
+        """One frame.  Returns the full image tensor on rank dst, None elsewhere.  `events`:
+        an optional (start, end) pair of torch.cuda.Event recorded around this rank's kernel."""
+        if events is not None:
+            events[0].record()
+        self.render_part(self.rank, self.world, self.send)
+        if events is not None:
+            events[1].record()
+        if self.world == 1:
+            self._assemble([self.send])
+            return self.image
+        dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        self._assemble(self.recv)
+        return self.image
+
+    def _assemble(self, parts):
+        for p, t in enumerate(parts):
+            n = api.part_rows(self.h, p, self.world)
+            if n == 0:
+                continue
+            if self.image.is_cuda and hasattr(self.render_part, "place"):
+                self.render_part.place(p, self.world, t, self.image)
+            else:
+                idx = torch.as_tensor(tile_rows(self.h, p, self.world), device=self.image.device)
+                self.image[idx] = t[:n]

@@ -79,9 +79,10 @@ class OracleScene:
     """scene -> prepare_scene -> render, as the reference's entry points chain them
     (ray.fut:176/223 -> :241 -> :246)."""
 
-    def __init__(self, name, n=None, k=None):
+    def __init__(self, name, n=None, k=None, spheres7=None, look_from=None, look_at=None, fov=None):
         L = lib()
         self.name = name
+        self._owns_spheres = True
         self.scene = Scene()
         if name == "rgbbox":
             rc = L.orc_scene_rgbbox(C.byref(self.scene))
@@ -91,6 +92,16 @@ class OracleScene:
             rc = L.orc_scene_floor(C.byref(self.scene), 1000 if n is None else n, 6000.0 if k is None else k)
         elif name == "floor":
             rc = L.orc_scene_floor(C.byref(self.scene), n, k)
+        elif name == "custom":
+            # spheres7: (n, 7) float32 {pos.xyz, colour.rgb, radius}; memory owned by numpy
+            self._spheres = np.ascontiguousarray(spheres7, dtype=np.float32)
+            self.scene.spheres = C.cast(self._spheres.ctypes.data, C.POINTER(Sphere))
+            self.scene.n = self._spheres.shape[0]
+            self.scene.look_from = Vec3(*look_from)
+            self.scene.look_at = Vec3(*look_at)
+            self.scene.fov = fov
+            self._owns_spheres = False
+            rc = 0
         else:
             raise ValueError(name)
         assert rc == 0
@@ -138,8 +149,9 @@ class OracleScene:
         L = lib()
         if self.bvh.n:
             L.orc_bvh_free(C.byref(self.bvh))
-        if self.scene.n:
+        if self.scene.n and self._owns_spheres:
             L.orc_scene_free(C.byref(self.scene))
+        self.scene.n = 0
 
     def __del__(self):
         try:

@@ -1,0 +1,317 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same deterministic inputs.  Bar: BIT-EXACT packed pixels and
+bit-exact BVH arrays -- there is no fp tolerance: the image is chaotic in the
+last ulp, so any deviation in operation order shows up as differing pixels."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = {"pixel": 1, "persistent": 2}
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raytracers_amd as R
+    return R
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    c = R.Context()
+    yield c
+    c.close()
+
+
+def _oracle(scene, **kw):
+    if scene.startswith("floor:"):
+        _, n, k = scene.split(":")
+        return O.OracleScene("floor", n=int(n), k=float(k))
+    return O.OracleScene(scene, **kw)
+
+
+def _scene(ctx, scene):
+    if scene.startswith("floor:"):
+        _, n, k = scene.split(":")
+        return ctx.floor(int(n), float(k))
+    return ctx.scene(scene)
+
+
+# ---------------------------------------------------------------- BVH + camera ------------
+@pytest.mark.parametrize("scene", ["rgbbox", "irreg", "floor:37:222", "floor:2:12"])
+def test_bvh_arrays_bit_exact(R, ctx, scene):
+    ps = R.prepare_scene(40, 56, _scene(ctx, scene))
+    got = ps.bvh_arrays()
+    want = _oracle(scene).arrays()
+    for k in ("left", "right", "parent"):
+        assert (got[k] == want[k]).all(), k
+    for k in ("L", "bmin", "bmax"):
+        assert got[k].tobytes() == want[k].tobytes(), k
+
+
+@pytest.mark.parametrize("h,w", [(200, 200), (500, 500), (1000, 1000), (37, 53), (1, 1), (4000, 4000), (480, 640)])
+def test_camera_bit_exact(R, ctx, h, w):
+    for scene in ("rgbbox", "irreg"):
+        ps = R.prepare_scene(h, w, ctx.scene(scene))
+        assert ps.camera().tobytes() == _oracle(scene).camera_floats(h, w).tobytes()
+
+
+# ---------------------------------------------------------------- pixels ------------------
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("scene", ["rgbbox", "irreg"])
+def test_golden_500(R, ctx, scene, variant):
+    """The reference's own known answers (rgbbox.png / irreg.png, decoded in tests/golden)."""
+    ctx.set_variant(VARIANTS[variant])
+    px = R.render(500, 500, R.prepare_scene(500, 500, ctx.scene(scene)))
+    assert int((px != O.load_golden(scene)).sum()) == 0
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("scene,h,w", [
+    ("rgbbox", 200, 200), ("irreg", 200, 200),          # BASELINE configs[0] size
+    ("rgbbox", 1000, 1000), ("irreg", 1000, 1000),      # BASELINE configs[1], [2]
+    ("rgbbox", 37, 53), ("irreg", 53, 37),              # ragged: partial 8x8 tiles on both edges
+    ("rgbbox", 1, 1), ("irreg", 1, 7), ("rgbbox", 9, 1),
+    ("floor:37:222", 120, 90), ("floor:2:12", 64, 64),  # other tree shapes (2 spheres: one inner node)
+])
+def test_pixels_bit_exact(R, ctx, scene, h, w, variant):
+    ctx.set_variant(VARIANTS[variant])
+    got = R.render(h, w, R.prepare_scene(h, w, _scene(ctx, scene)))
+    want, _ = _oracle(scene).render(h, w)
+    assert got.shape == want.shape
+    assert int((got != want).sum()) == 0
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("max_depth", [0, 1, 2, 3, 50])
+def test_bounce_limit(R, ctx, variant, max_depth):
+    """configs[0] reads '1 bounce': max_depth 1 gives one ray per pixel (sky or black)."""
+    ctx.set_variant(VARIANTS[variant])
+    got = R.render(96, 120, R.prepare_scene(96, 120, ctx.rgbbox()), max_depth=max_depth)
+    want, _ = _oracle("rgbbox").render(96, 120, max_depth=max_depth)
+    assert int((got != want).sum()) == 0
+
+
+def test_irreg_4000_strong_scaling_config(R, ctx):
+    """BASELINE configs[3] size on one GPU: full-size parity against the oracle."""
+    ctx.set_variant(0)
+    got = R.render(4000, 4000, R.prepare_scene(4000, 4000, ctx.irreg()))
+    want, _ = _oracle("irreg").render(4000, 4000)
+    assert O.checksum(got) == O.checksum(want) == 0xDB269D43
+    assert int((got != want).sum()) == 0
+
+
+def test_big_scene_million_spheres(R, ctx):
+    """BASELINE configs[4] scene (irreg generator at n=1000, k=6000 -> 10^6 spheres, tree
+    height 20, BVH far larger than LDS): BVH arrays and a 512x512 render, bit-exact."""
+    ctx.set_variant(0)
+    ps = R.prepare_scene(512, 512, ctx.scene("big"))
+    orc = _oracle("big")
+    got, want = ps.bvh_arrays(), orc.arrays()
+    for k in ("left", "right", "parent"):
+        assert (got[k] == want[k]).all(), k
+    for k in ("L", "bmin", "bmax"):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    px = R.render(512, 512, ps)
+    ref, _ = orc.render(512, 512)
+    assert int((px != ref).sum()) == 0
+    ctx.set_variant(1)
+    assert int((R.render(512, 512, ps) != ref).sum()) == 0
+
+
+def test_random_scene_with_duplicates_and_explicit_camera(R, ctx):
+    """Arbitrary spheres through rt_scene_from_spheres, including exact duplicates (equal
+    Morton keys -> index tie-break in the radix tree; coincident spheres -> lowest leaf index
+    wins) and render_image with an explicit camera."""
+    rng = np.random.default_rng(1234)
+    n = 600
+    s = np.zeros((n, 7), np.float32)
+    s[:, 0:3] = rng.uniform(-40, 40, (n, 3))
+    s[:, 3:6] = rng.uniform(0.2, 1.0, (n, 3))
+    s[:, 6] = rng.uniform(0.5, 4.0, n)
+    s[100:140, 0:3] = s[0:40, 0:3]          # coincident centres, different colours/radii
+    s[140:150] = s[40:50]                   # exact duplicates
+    lf, la, fov = (5.0, 25.0, 70.0), (0.0, 0.0, 0.0), 60.0
+    orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
+    for variant in (1, 2):
+        ctx.set_variant(variant)
+        ps = R.prepare_scene(150, 200, ctx.scene_from_spheres(s, lf, la, fov))
+        got, want = ps.bvh_arrays(), orc.arrays()
+        for k in ("left", "right", "parent"):
+            assert (got[k] == want[k]).all(), k
+        for k in ("L", "bmin", "bmax"):
+            assert got[k].tobytes() == want[k].tobytes(), k
+        px = R.render(150, 200, ps)
+        ref, _ = orc.render(150, 200)
+        assert int((px != ref).sum()) == 0
+        # explicit camera: the prepared camera of ANOTHER size, passed by hand
+        cam = orc.camera_floats(90, 160)
+        px2 = R.render_image(ps, 160, 90, cam)
+        ref2, _ = orc.render(90, 160)
+        assert int((px2 != ref2).sum()) == 0
+
+
+# ---------------------------------------------------------------- work counters -----------
+@pytest.mark.parametrize("scene,h", [("rgbbox", 200), ("irreg", 200), ("rgbbox", 1000), ("irreg", 1000)])
+def test_work_counters_match_oracle(R, ctx, scene, h):
+    ps = R.prepare_scene(h, h, ctx.scene(scene))
+    _, cnt = _oracle(scene).render(h, h)
+    st = ps.stats()
+    assert st == {k: cnt[k] for k in ("rays", "box_tests", "leaf_tests")}
+
+
+# ---------------------------------------------------------------- knobs keep parity -------
+@pytest.mark.parametrize("opts", [
+    dict(waves_per_wg=4, wgs_per_cu=4), dict(waves_per_wg=16, wgs_per_cu=1), dict(thr_shade=1, thr_leaf=1),
+    dict(thr_shade=64, thr_leaf=64), dict(lmax=2), dict(lmax=16), dict(lds_scene_bytes=0),
+    dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192),
+])
+def test_persistent_knobs_do_not_change_pixels(R, opts):
+    c = R.Context()
+    c.set_variant(2)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    for scene in ("rgbbox", "irreg"):
+        got = R.render(120, 136, R.prepare_scene(120, 136, c.scene(scene)))
+        want, _ = _oracle(scene).render(120, 136)
+        assert int((got != want).sum()) == 0, (scene, opts)
+    c.close()
+
+
+def test_repeated_launches_share_the_ticket_counter(R, ctx):
+    """The persistent family's work queue is a monotonic counter that is never reset."""
+    ctx.set_variant(2)
+    ps_a = R.prepare_scene(64, 64, ctx.rgbbox())
+    ps_b = R.prepare_scene(100, 36, ctx.irreg())
+    wa, _ = _oracle("rgbbox").render(64, 64)
+    wb, _ = _oracle("irreg").render(100, 36)
+    for _ in range(20):
+        assert (R.render(64, 64, ps_a) == wa).all()
+        assert (R.render(100, 36, ps_b) == wb).all()
+
+
+# ---------------------------------------------------------------- row-tile partition ------
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_parts_assemble_to_the_full_image(R, ctx, variant, nparts):
+    import torch
+    ctx.set_variant(VARIANTS[variant])
+    h, w = 203, 96
+    ps = R.prepare_scene(h, w, ctx.irreg())
+    want, _ = _oracle("irreg").render(h, w)
+    image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+    for p in range(nparts):
+        rows = R.part_rows(h, p, nparts)
+        part = torch.empty((max(rows, 1), w), dtype=torch.int32, device="cuda")
+        R.render_into(part.data_ptr(), h, w, ps, part=p, nparts=nparts)
+        R.place_part(ctx, h, w, p, nparts, part.data_ptr(), image.data_ptr())
+    ctx.sync()
+    torch.cuda.synchronize()
+    assert int((image.cpu().numpy() != want).sum()) == 0
+
+
+def test_sharded_renderer_single_rank_on_torch_stream(R):
+    import torch
+    from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
+    h, w = 200, 200
+    pr = HipPartRenderer("rgbbox", h, w, "cuda:0")
+    sr = ShardedRenderer(pr, h, w, device="cuda:0")
+    img = sr.render()
+    torch.cuda.synchronize()
+    want, _ = _oracle("rgbbox").render(h, w)
+    assert int((img.cpu().numpy() != want).sum()) == 0
+
+
+# ---------------------------------------------------------------- the drop-in boundary ----
+def test_futhark_abi_call_sequence(R):
+    """The exact call sequence of futhark/main.c:59-141 through ctypes."""
+    from raytracers_amd._lib import lib
+    vp = C.c_void_p
+    lib.futhark_context_config_new.restype = vp
+    lib.futhark_context_new.restype = vp
+    lib.futhark_context_new.argtypes = [vp]
+    lib.futhark_context_get_error.restype = vp
+    lib.futhark_context_get_error.argtypes = [vp]
+    cfg = vp(lib.futhark_context_config_new())
+    fctx = vp(lib.futhark_context_new(cfg))
+    assert lib.futhark_context_get_error(fctx) is None
+    for name, entry in (("rgbbox", lib.futhark_entry_rgbbox), ("irreg", lib.futhark_entry_irreg)):
+        scene, ps, img = vp(), vp(), vp()
+        entry.argtypes = [vp, C.POINTER(vp)]
+        assert entry(fctx, C.byref(scene)) == 0
+        lib.futhark_entry_prepare_scene.argtypes = [vp, C.POINTER(vp), C.c_int64, C.c_int64, vp]
+        lib.futhark_entry_render.argtypes = [vp, C.POINTER(vp), C.c_int64, C.c_int64, vp]
+        lib.futhark_values_i32_2d.argtypes = [vp, vp, vp]
+        lib.futhark_context_sync.argtypes = [vp]
+        h, w = 120, 200   # h != w: catches an h/w swap at the boundary
+        for _ in range(2):
+            if ps:
+                lib.futhark_free_opaque_prepared_scene.argtypes = [vp, vp]
+                lib.futhark_free_opaque_prepared_scene(fctx, ps)
+            assert lib.futhark_entry_prepare_scene(fctx, C.byref(ps), h, w, scene) == 0
+            assert lib.futhark_context_sync(fctx) == 0
+        for _ in range(2):
+            if img:
+                lib.futhark_free_i32_2d.argtypes = [vp, vp]
+                lib.futhark_free_i32_2d(fctx, img)
+            assert lib.futhark_entry_render(fctx, C.byref(img), h, w, ps) == 0
+            assert lib.futhark_context_sync(fctx) == 0
+        host = np.empty((h, w), np.int32)
+        assert lib.futhark_values_i32_2d(fctx, img, host.ctypes.data) == 0
+        want, _ = _oracle(name).render(h, w)
+        assert int((host != want).sum()) == 0
+        lib.futhark_free_i32_2d.argtypes = [vp, vp]
+        lib.futhark_free_opaque_prepared_scene.argtypes = [vp, vp]
+        lib.futhark_free_opaque_scene.argtypes = [vp, vp]
+        lib.futhark_free_i32_2d(fctx, img)
+        lib.futhark_free_opaque_prepared_scene(fctx, ps)
+        lib.futhark_free_opaque_scene(fctx, scene)
+    lib.futhark_context_free.argtypes = [vp]
+    lib.futhark_context_config_free.argtypes = [vp]
+    lib.futhark_context_free(fctx)
+    lib.futhark_context_config_free(cfg)
+
+
+def _read_ppm(path):
+    tok = open(path).read().split()
+    assert tok[0] == "P3"
+    w, h = int(tok[1]), int(tok[2])
+    v = np.array(tok[4:], dtype=np.int32).reshape(h, w, 3)
+    return (v[..., 0] << 16) | (v[..., 1] << 8) | v[..., 2]
+
+
+@pytest.mark.parametrize("scene", ["rgbbox", "irreg"])
+def test_reference_harness_unmodified(scene, tmp_path):
+    """oracle/_ref/futhark_main is the reference's own futhark/main.c, compiled unmodified in
+    the build container against include/ray.h; here it runs on the GPU against our library and
+    its PPM output must equal the oracle's image."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "futhark_main")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/futhark_main was not prebuilt (needs /root/reference)")
+    ppm = str(tmp_path / "out.ppm")
+    # main.c: -n is the height, -m the width (main.c:36-41)
+    out = subprocess.run([exe, "-s", scene, "-n", "300", "-m", "400", "-r", "3", "-f", ppm], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Rendering in" in out.stdout and "Scene BVH construction in" in out.stdout
+    want, _ = _oracle(scene).render(300, 400)
+    assert int((_read_ppm(ppm) != want).sum()) == 0
+
+
+def test_native_bench_runs(tmp_path):
+    exe = os.path.join(ROOT, "build", "rtbench")
+    if not os.path.exists(exe):
+        pytest.skip("build/rtbench not built")
+    ppm = str(tmp_path / "p.ppm")
+    out = subprocess.run([exe, "-s", "irreg", "-n", "160", "-m", "120", "-r", "2", "-g", "3", "-f", ppm],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want, _ = _oracle("irreg").render(160, 120)
+    assert int((_read_ppm(ppm) != want).sum()) == 0
