@@ -39,9 +39,11 @@ enum {
 };
 
 /* ---- context ------------------------------------------------------------------ */
-/* device < 0: the current HIP device.  stream == NULL: the context creates and owns
- * a stream; otherwise the caller's hipStream_t is used (e.g. torch's current stream). */
-int rt_context_create(rt_context **out, int device, void *hip_stream);
+/* device < 0: the current HIP device.  use_caller_stream == 0: the context creates and
+ * owns a non-blocking stream (hip_stream is ignored).  use_caller_stream != 0: all work is
+ * enqueued on the caller's hipStream_t `hip_stream` -- NULL then means the default stream
+ * (which is what torch.cuda.current_stream().cuda_stream is unless the caller switched). */
+int rt_context_create(rt_context **out, int device, void *hip_stream, int use_caller_stream);
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
 int rt_context_sync(rt_context *ctx);

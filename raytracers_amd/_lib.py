@@ -49,7 +49,7 @@ def _load():
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     pf = C.POINTER(C.c_float)
     sig = {
-        "rt_context_create": (C.c_int, [C.POINTER(vp), C.c_int, vp]),
+        "rt_context_create": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.c_int]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, [vp]),
         "rt_context_sync": (C.c_int, [vp]),

@@ -25,12 +25,14 @@ class RtError(RuntimeError):
 
 
 class Context:
-    """One HIP device + one stream.  `stream` may be a raw hipStream_t (int), e.g.
-    torch.cuda.current_stream().cuda_stream, so that launches order with torch work."""
+    """One HIP device + one stream.  stream=None: the context owns a private stream.
+    Otherwise `stream` is a raw hipStream_t as an int, e.g.
+    torch.cuda.current_stream().cuda_stream (0 = the default stream), so that launches order
+    with torch work and torch.cuda.Event timing sees them."""
 
     def __init__(self, device=-1, stream=None):
         h = C.c_void_p()
-        rc = lib.rt_context_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        rc = lib.rt_context_create(C.byref(h), int(device), C.c_void_p(stream or 0), 0 if stream is None else 1)
         if rc != 0 or not h.value:
             raise RtError(f"rt_context_create failed (code {rc}): no usable HIP device; "
                           "raytracers_amd has no CPU fallback")

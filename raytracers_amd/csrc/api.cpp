@@ -104,7 +104,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   pl->lmax = ctx->lmax;
   pl->waves = ctx->waves_per_wg;
   const int total = std::min(ctx->lds_bytes, 160 * 1024) / std::max(1, ctx->wgs_per_cu);
-  const int scratch = pl->waves * (pl->smax + pl->lmax) * 64 * 4;
+  const int scratch = pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
   int budget = total - scratch - 512;
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   if (budget < 0) return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
@@ -136,6 +136,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   RT_HIP(ctx, hipSetDevice(ctx->device));
   rtk::KParams p{};
   p.nodes = ps->nodes; p.sph = ps->sph; p.col = ps->col;
+  p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
   std::memcpy(&p.cam, cam12 ? static_cast<const void *>(cam12) : static_cast<const void *>(&ps->cam), sizeof(p.cam));
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
   p.rows_local = static_cast<int>(rt::part_rows(h, rows_per_tile, part, nparts));
@@ -171,7 +172,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
 }  // namespace
 
 // ------------------------------------------------------------------------------------ context
-extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream) {
+extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream, int use_caller_stream) {
   if (!out) return 1;
   *out = nullptr;
   auto ctx = std::make_unique<rt_context>();
@@ -194,8 +195,8 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream)
   ctx->lds_bytes = static_cast<int>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
                                                                            : prop.sharedMemPerBlock);
   ctx->name = prop.gcnArchName;
-  if (hip_stream) {
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+  if (use_caller_stream) {
+    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL is a valid handle: the default stream
   } else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return 6;
     ctx->own_stream = true;
@@ -516,7 +517,7 @@ extern "C" void futhark_context_config_set_device(struct futhark_context_config 
 extern "C" struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) {
   auto ctx = std::make_unique<futhark_context>();
   ctx->logging = cfg ? (cfg->logging | cfg->debugging) : 0;
-  const int rc = rt_context_create(&ctx->rt, cfg ? cfg->device : -1, nullptr);
+  const int rc = rt_context_create(&ctx->rt, cfg ? cfg->device : -1, nullptr, 0);
   if (rc) {
     // Futhark returns a context whose error is set; main.c asserts it is NULL.
     ctx->pending = "libray_mi355x: cannot create a HIP context (code " + std::to_string(rc) + "); no CPU path exists";

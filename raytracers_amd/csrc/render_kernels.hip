@@ -22,6 +22,19 @@ namespace rtk {
 
 __device__ __forceinline__ int f2i(float f) { return __float_as_int(f); }
 
+// 16-byte global load through a buffer resource (buffer_load_dwordx4, base in SGPRs, 32-bit
+// byte offset per lane).  Used for the part of the scene that is NOT staged in LDS: an
+// ordinary pointer load next to an LDS load gets if-converted by hipcc into one flat_load
+// with a selected address, which is far slower than ds_read / buffer_load.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+  const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
 // local (packed) row of this part -> row of the full image, cyclic row tiles
 __device__ __forceinline__ int global_row(const KParams &p, int lrow) {
   const int k = lrow / p.rows_per_tile;
@@ -41,6 +54,8 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int col = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
   if (col >= p.w || lrow >= p.rows_local) return;
+  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes, (unsigned)p.n_nodes * 32u);
+  const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
   Ray r = primary_ray(p.cam, col, global_row(p, lrow), p.w, p.h);
   float lr = 1.0f, lg = 1.0f, lb = 1.0f;
   int depth = 0;
@@ -54,16 +69,17 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
     if (STATS) n_rays++;
     while (sp > 0) {
       const int ni = stack[--sp][lane];
-      const float4 lo = p.nodes[2 * ni], hi = p.nodes[2 * ni + 1];
+      const float4 lo = buf_load16(rs_nodes, ni * 32), hi = buf_load16(rs_nodes, ni * 32 + 16);
+      const int kids[2] = {f2i(lo.w), f2i(hi.w)};
+      asm volatile("" ::"v"(kids[0]), "v"(kids[1]));   // keep the child refs in the first load (no sunk re-load)
       if (STATS) n_box++;
       if (!box_hit(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) continue;
-      const int kids[2] = {f2i(lo.w), f2i(hi.w)};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int c = kids[k];
         if (c < 0) {
           const int j = ~c;
-          const float4 s = p.sph[j];
+          const float4 s = buf_load16(rs_sph, j * 16);
           if (STATS) n_sph++;
           closest_update(sphere_root(r, s.x, s.y, s.z, s.w), j, best, bestj);
         } else {
@@ -103,9 +119,12 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
   const int wave = threadIdx.x >> 6;
   // per-wave scratch: stack[SMAX][64] then leaves[LMAX][64]; entry-major so that one
   // entry of all 64 lanes is 64 consecutive dwords (bank = lane, conflict-free)
-  int *const wstack = reinterpret_cast<int *>(lsph + p.lds_sph) + wave * ((SMAX + LMAX) * 64) + lane;
-  int *const wleaf = wstack + SMAX * 64;
+  int *const wstack = reinterpret_cast<int *>(lsph + p.lds_sph) + wave * ((SMAX + 1 + LMAX) * 64) + lane;
+  int *const wleaf = wstack + (SMAX + 1) * 64;
 
+  const int sph_base = 2 * p.lds_nodes;
+  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes, (unsigned)p.n_nodes * 32u);
+  const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
   for (int i = threadIdx.x; i < 2 * p.lds_nodes; i += THREADS) lnodes[i] = p.nodes[i];
   for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) lsph[i] = p.sph[i];
   __syncthreads();
@@ -141,33 +160,40 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 
     if (op == 0) {
       // ---- BOX: one inner node per lane ----
+      // Written predicated rather than branchy: both float4 of the node are loaded and
+      // consumed unconditionally (hipcc otherwise sinks the child-reference dwords into the
+      // hit branch = a second dependent memory round trip), and the LDS / global choice is a
+      // value merge of two separate loads (a pointer select would become flat_load).
       if (can_box) {
-        int ni = cur;
-        if (ni < 0) ni = wstack[(--sp) * 64];
-        float4 lo, hi;
-        if (ni < p.lds_nodes) {
-          lo = lnodes[2 * ni];
-          hi = lnodes[2 * ni + 1];
-        } else {
-          lo = p.nodes[2 * ni];
-          hi = p.nodes[2 * ni + 1];
+        const bool pop = cur < 0;
+        sp -= pop ? 1 : 0;
+        const int popped = wstack[sp * 64];          // slot sp exists (SMAX + 1 entries per lane)
+        const int ni = pop ? popped : cur;
+        const int li = ni < p.lds_nodes ? ni : 0;
+        float4 lo = smem[2 * li], hi = smem[2 * li + 1];
+        if (ni >= p.lds_nodes) {
+          lo = buf_load16(rs_nodes, ni * 32);
+          hi = buf_load16(rs_nodes, ni * 32 + 16);
         }
+        const int cl = f2i(lo.w), cr = f2i(hi.w);
         if (STATS) n_box++;
-        int next = -1;
-        if (box_hit(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) {
-          const int cl = f2i(lo.w), cr = f2i(hi.w);
-          if (cl < 0) wleaf[(nl++) * 64] = ~cl; else next = cl;
-          if (cr < 0) wleaf[(nl++) * 64] = ~cr;
-          else if (next < 0) next = cr;
-          else wstack[(sp++) * 64] = cr;
-        }
-        cur = next;
+        const bool hit = box_hit(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+        const bool lfl = hit & (cl < 0), lfr = hit & (cr < 0);
+        const bool inl = hit & (cl >= 0), inr = hit & (cr >= 0);
+        if (lfl) wleaf[nl * 64] = ~cl;
+        nl += lfl ? 1 : 0;
+        if (lfr) wleaf[nl * 64] = ~cr;
+        nl += lfr ? 1 : 0;
+        if (inl & inr) wstack[sp * 64] = cr;
+        sp += (inl & inr) ? 1 : 0;
+        cur = inl ? cl : (inr ? cr : -1);
       }
     } else if (op == 1) {
       // ---- LEAF: one deferred sphere test per lane ----
       if (can_leaf) {
         const int j = wleaf[(--nl) * 64];
-        const float4 s = (j < p.lds_sph) ? lsph[j] : p.sph[j];
+        float4 s = smem[sph_base + (j < p.lds_sph ? j : 0)];
+        if (j >= p.lds_sph) s = buf_load16(rs_sph, j * 16);
         if (STATS) n_sph++;
         closest_update(sphere_root(r, s.x, s.y, s.z, s.w), j, best, bestj);
       }
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
       if (idle & (pix >= 0)) {
         float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bestj >= 0) {
-          s = (bestj < p.lds_sph) ? lsph[bestj] : p.sph[bestj];
+          s = p.sph[bestj];
           c = p.col[bestj];
         }
         int32_t pixel;
@@ -268,7 +294,7 @@ hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream) {
 }
 
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg) {
-  return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (smax + lmax) * 64 * sizeof(int);
+  return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (smax + 1 + lmax) * 64 * sizeof(int);
 }
 
 template <int THREADS, bool STATS>

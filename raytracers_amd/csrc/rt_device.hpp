@@ -14,6 +14,7 @@ struct KParams {
   const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
   const float4 *sph;     // [n] {pos.xyz, radius}
   const float4 *col;     // [n] {colour.rgb, 0}
+  int n_nodes, n_sph;    // n-1, n
   Cam cam;
   // image + partition
   int w, h;              // full image

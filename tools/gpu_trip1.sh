@@ -29,7 +29,7 @@ done
 timeout 600 python bench.py --steps 50 --warmup 10 > $OUT/04_bench.json 2> $OUT/04_bench.err
 timeout 600 python bench.py --steps 50 --warmup 10 --variant 1 --no-cpu-baseline > $OUT/04_bench_pixel.json 2>> $OUT/04_bench.err
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof_bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OLDPWD/$OUT/05_rocprof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OLDPWD/$OUT/05_rocprof_bench.log 2>&1
 cd $OLDPWD
 rocprofv3 -L > $OUT/counters.txt 2>&1
 find $OUT/prof_bench -name "*stats*" | head -20 > $OUT/prof_files.txt

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
     }
   }
   rt_context *ctx = NULL;
-  if (rt_context_create(&ctx, -1, NULL) != 0) { fprintf(stderr, "no HIP device\n"); return 1; }
+  if (rt_context_create(&ctx, -1, NULL, 0) != 0) { fprintf(stderr, "no HIP device\n"); return 1; }
   CHECK(ctx, rt_context_set_variant(ctx, variant));
   for (int i = 0; i < nopts; i++) {
     char key[64];
@@ -148,6 +148,8 @@ int main(int argc, char **argv) {
       CHECK(ctx, rt_device_alloc(ctx, (void **)&full, (int64_t)sizeof(int32_t) * h * w));
       int64_t off = 0;
       for (int p = 0; p < parts; p++) {
+        /* img was reused by the timed full-frame launches above: render the parts again */
+        CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, p, parts, img + off));
         CHECK(ctx, rt_place_part(ctx, h, w, 8, p, parts, img + off, full));
         off += rt_part_rows(h, 8, p, parts) * w;
       }
