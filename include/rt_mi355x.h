@@ -34,8 +34,10 @@ typedef struct rt_prepared rt_prepared;  /* `prepared_scene` (ray.fut:239): devi
 enum {
   RT_VARIANT_AUTO = 0,        /* best known configuration for the scene size */
   RT_VARIANT_PIXEL = 1,       /* one thread per pixel, BVH in HBM/L2, no LDS staging (BASELINE configs[1]) */
-  RT_VARIANT_PERSISTENT = 2   /* persistent waves: work queue + in-place lane refill + phase voting,
+  RT_VARIANT_PERSISTENT = 2,  /* persistent waves: work queue + in-place lane refill + phase voting,
                                  top BVH levels staged in LDS (BASELINE configs[2]) */
+  RT_VARIANT_POOLED = 3       /* persistent waves whose lanes share LDS work lists of (ray slot, node)
+                                 items: any lane tests any ray's node; ballot/mbcnt compaction */
 };
 
 /* ---- context ------------------------------------------------------------------ */

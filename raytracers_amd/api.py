@@ -15,7 +15,7 @@ import numpy as np
 
 from ._lib import lib
 
-VARIANT_AUTO, VARIANT_PIXEL, VARIANT_PERSISTENT = 0, 1, 2
+VARIANT_AUTO, VARIANT_PIXEL, VARIANT_PERSISTENT, VARIANT_POOLED = 0, 1, 2, 3
 MAX_DEPTH = 50          # ray.fut:154
 ROWS_PER_TILE = 8       # cyclic row-tile height of the multi-GPU partition
 

@@ -86,6 +86,7 @@ int upload(rt_context *ctx, T **dev, const void *host, size_t bytes) {
 struct Plan {
   int variant;
   int lds_nodes, lds_sph, smax, lmax, waves, grid;
+  int capb, capl;
   size_t lds_bytes;
 };
 
@@ -104,7 +105,11 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   pl->lmax = ctx->lmax;
   pl->waves = ctx->waves_per_wg;
   const int total = std::min(ctx->lds_bytes, 160 * 1024) / std::max(1, ctx->wgs_per_cu);
-  const int scratch = pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
+  // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
+  pl->capb = 64 * (ps->height + 3);
+  pl->capl = 256;
+  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (192 + pl->capb + pl->capl) * 4
+                                                       : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
   int budget = total - scratch - 512;
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   if (budget < 0) return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
@@ -118,7 +123,8 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   }
   pl->lds_nodes = ln;
   pl->lds_sph = ls;
-  pl->lds_bytes = rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
+  pl->lds_bytes = pl->variant == RT_VARIANT_POOLED ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
+                                                   : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
   pl->grid = ctx->num_cu * ctx->wgs_per_cu;
   return 0;
 }
@@ -164,7 +170,9 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
-  RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
+  p.capb = pl.capb; p.capl = pl.capl;
+  if (pl.variant == RT_VARIANT_POOLED) RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+  else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
   ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
   return 0;
 }
@@ -230,7 +238,7 @@ extern "C" int rt_context_sync(rt_context *ctx) {
 
 extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
   if (!ctx) return 1;
-  if (variant < RT_VARIANT_AUTO || variant > RT_VARIANT_PERSISTENT) return fail(ctx, "unknown variant");
+  if (variant < RT_VARIANT_AUTO || variant > RT_VARIANT_POOLED) return fail(ctx, "unknown variant");
   ctx->variant = variant;
   return 0;
 }

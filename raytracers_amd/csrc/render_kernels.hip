@@ -268,6 +268,210 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// Family 3: pooled work items.
+//
+// A wave owns 64 ray SLOTS (slot i's ray lives in lane i's registers) and two work lists in
+// LDS that all lanes share: a LIFO stack of (slot, inner node) items and a list of
+// (slot, leaf) items.  ANY lane processes ANY item -- it pulls the ray it needs from the
+// owning lane with ds_bpermute -- so a traversal step is one dense wave-wide operation
+// whatever the per-ray traversal lengths are, and one ray's subtree is searched by many
+// lanes at once (the fixed (0, 1e9) box interval makes the box tests of a ray independent
+// of its hits, so any order gives the fold's result).  Children are appended with
+// ballot + mbcnt prefix sums.  Per slot, an outstanding-item counter (LDS atomic add) tells
+// when the fold is complete, and the closest hit is an LDS 64-bit atomic min over
+// (bits(t) << 32 | leaf index): smallest t, ties to the lowest leaf index -- exactly
+// closest_hit's accumulator (ray.fut:78-81).
+//
+// Bound on the box stack (H = tree height): each operation pops the <= 64 newest items and
+// pushes their <= 128 children, whose depth exceeds their parents'; remainders of at most
+// 64 items per "generation" with strictly increasing depth labels => size <= 64*H + 128.
+// The leaf list is drained first whenever it holds >= 64 items => size <= 63 + 128.
+// ---------------------------------------------------------------------------------
+constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
+
+__device__ __forceinline__ float pull(int lane_byte, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
+}
+
+template <int THREADS, bool STATS>
+__global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
+  extern __shared__ float4 smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sph_base = 2 * p.lds_nodes;
+  // per-wave region: key[64] (u64) | cnt[64] | box stack[capb] | leaf list[capl]
+  const int per_wave_dw = 128 + 64 + p.capb + p.capl;
+  unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
+  unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
+  int *const wcnt = reinterpret_cast<int *>(wbase + 128);
+  unsigned *const wbox = wbase + 192;
+  unsigned *const wleaf = wbox + p.capb;
+  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes, (unsigned)p.n_nodes * 32u);
+  const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
+
+  for (int i = threadIdx.x; i < 2 * p.lds_nodes; i += THREADS) smem[i] = p.nodes[i];
+  for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) smem[sph_base + i] = p.sph[i];
+  wcnt[lane] = 0;
+  wkey[lane] = kKeyInit;
+  __syncthreads();
+
+  // ---- slot state, owned by this lane ----
+  Ray r = {};
+  float lr = 1.0f, lg = 1.0f, lb = 1.0f;
+  int depth = 0;
+  int pix = -1;            // -1: slot empty
+  unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
+  // ---- wave state (uniform) ----
+  int nbox = 0, nleaf = 0;
+  unsigned q_next = 0, q_end = 0;
+  bool exhausted = false;
+
+  for (;;) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int op;   // 0 box, 1 leaf, 2 shade
+    if (nleaf >= 64) op = 1;
+    else if (nbox >= 64) op = 0;
+    else {
+      const bool done = (pix >= 0) & (wcnt[lane] == 0);
+      const bool vacant = (pix < 0) & !exhausted;
+      const int ns = __popcll(__ballot(done | vacant));
+      if (ns >= p.thr_shade || (nbox == 0 && nleaf == 0)) {
+        if (ns == 0) break;
+        op = 2;
+      } else op = nbox > 0 ? 0 : 1;
+    }
+
+    if (op == 0) {
+      // ---- BOX: up to 64 (slot, node) items ----
+      const int n = nbox < 64 ? nbox : 64;
+      const bool act = lane < n;
+      const unsigned item = wbox[act ? nbox - 1 - lane : 0];
+      nbox -= n;
+      const int sl4 = act ? (int)(item >> 26) * 4 : lane * 4;
+      const int ni = act ? (int)(item & 0x3ffffffu) : 0;
+      Ray q;
+      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
+      q.ix = pull(sl4, r.ix); q.iy = pull(sl4, r.iy); q.iz = pull(sl4, r.iz);
+      const int li = ni < p.lds_nodes ? ni : 0;
+      float4 lo = smem[2 * li], hi = smem[2 * li + 1];
+      if (ni >= p.lds_nodes) {
+        lo = buf_load16(rs_nodes, ni * 32);
+        hi = buf_load16(rs_nodes, ni * 32 + 16);
+      }
+      const int cl = f2i(lo.w), cr = f2i(hi.w);
+      const bool hit = act & box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+      if (STATS) n_box += act ? 1 : 0;
+      const bool inl = hit & (cl >= 0), inr = hit & (cr >= 0);
+      const bool lfl = hit & (cl < 0), lfr = hit & (cr < 0);
+      const unsigned long long m_inl = __ballot(inl), m_inr = __ballot(inr);
+      const unsigned long long m_lfl = __ballot(lfl), m_lfr = __ballot(lfr);
+      const unsigned tag = item & 0xfc000000u;
+      const int pin = nbox + lane_rank(m_inl) + lane_rank(m_inr);
+      if (inl) wbox[pin] = tag | (unsigned)cl;
+      if (inr) wbox[pin + (inl ? 1 : 0)] = tag | (unsigned)cr;
+      nbox += __popcll(m_inl) + __popcll(m_inr);
+      const int plf = nleaf + lane_rank(m_lfl) + lane_rank(m_lfr);
+      if (lfl) wleaf[plf] = tag | (unsigned)~cl;
+      if (lfr) wleaf[plf + (lfl ? 1 : 0)] = tag | (unsigned)~cr;
+      nleaf += __popcll(m_lfl) + __popcll(m_lfr);
+      // one item consumed, two created on a hit: outstanding += hit ? +1 : -1
+      if (act) atomicAdd(&wcnt[sl4 >> 2], hit ? 1 : -1);
+    } else if (op == 1) {
+      // ---- LEAF: up to 64 (slot, sphere) items ----
+      const int n = nleaf < 64 ? nleaf : 64;
+      const bool act = lane < n;
+      const unsigned item = wleaf[act ? nleaf - 1 - lane : 0];
+      nleaf -= n;
+      const int sl4 = act ? (int)(item >> 26) * 4 : lane * 4;
+      const int j = act ? (int)(item & 0x3ffffffu) : 0;
+      Ray q;
+      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
+      q.dx = pull(sl4, r.dx); q.dy = pull(sl4, r.dy); q.dz = pull(sl4, r.dz);
+      q.a = pull(sl4, r.a);
+      float4 s = smem[sph_base + (j < p.lds_sph ? j : 0)];
+      if (j >= p.lds_sph) s = buf_load16(rs_sph, j * 16);
+      if (STATS) n_sph += act ? 1 : 0;
+      const float g = sphere_root(q, s.x, s.y, s.z, s.w);
+      if (act & (g < kTMax))
+        atomicMin(&wkey[sl4 >> 2], ((unsigned long long)__float_as_uint(g) << 32) | (unsigned)j);
+      if (act) atomicAdd(&wcnt[sl4 >> 2], -1);
+    } else {
+      // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
+      bool root = false;
+      if ((pix >= 0) & (wcnt[lane] == 0)) {
+        const unsigned long long key = wkey[lane];
+        const float best = __uint_as_float((unsigned)(key >> 32));
+        const int bestj = key == kKeyInit ? -1 : (int)(unsigned)(key & 0xffffffffull);
+        float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bestj >= 0) {
+          s = p.sph[bestj];
+          c = p.col[bestj];
+        }
+        int32_t pixel;
+        if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          root = true;
+        } else {
+          p.out[pix] = pixel;
+          pix = -1;
+        }
+      }
+      bool want = (pix < 0) & !exhausted;
+      int slot = -1;
+      unsigned long long m = __ballot(want);
+      while (m != 0ull) {            // wave-uniform loop
+        if (q_next == q_end) {
+          unsigned t = 0;
+          if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
+          t = __builtin_amdgcn_readfirstlane(t);
+          if (t >= (unsigned)p.nchunks) {
+            exhausted = true;
+            break;
+          }
+          q_next = t * 64u;
+          q_end = q_next + 64u;
+        }
+        const unsigned avail = q_end - q_next;
+        const unsigned rank = (unsigned)lane_rank(m);
+        const unsigned cnt = (unsigned)__popcll(m);
+        if (want & (rank < avail)) {
+          const unsigned sidx = q_next + rank;
+          const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
+          const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+          const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+          if (col < p.w && lrow < p.rows_local) {
+            slot = lrow * p.w + col;
+            want = false;
+          }
+        }
+        q_next += (cnt < avail) ? cnt : avail;
+        m = __ballot(want);
+      }
+      if (slot >= 0) {
+        const int lrow = slot / p.w, col = slot - lrow * p.w;
+        r = primary_ray(p.cam, col, global_row(p, lrow), p.w, p.h);
+        lr = 1.0f; lg = 1.0f; lb = 1.0f;
+        depth = 0;
+        pix = slot;
+        root = true;
+      }
+      if (root) {
+        wkey[lane] = kKeyInit;
+        wcnt[lane] = 1;
+        if (STATS) n_rays++;
+      }
+      const unsigned long long m_root = __ballot(root);
+      if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 26;   // (slot = lane, node 0)
+      nbox += __popcll(m_root);
+    }
+  }
+  if (STATS) {
+    atomicAdd(&p.stats[0], n_rays);
+    atomicAdd(&p.stats[1], n_box);
+    atomicAdd(&p.stats[2], n_sph);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Framebuffer assembly: scatter one part's packed rows into the full image.
 // ---------------------------------------------------------------------------------
 __global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile,
@@ -319,6 +523,36 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
   case 4: return launch_persistent_t<256, false>(p, grid, stream);
   case 8: return launch_persistent_t<512, false>(p, grid, stream);
   case 16: return launch_persistent_t<1024, false>(p, grid, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg) {
+  return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (192 + capb + capl) * sizeof(unsigned);
+}
+
+template <int THREADS, bool STATS>
+static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
+  const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, THREADS / 64);
+  auto kfn = pooled_kernel<THREADS, STATS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
+  if (grid <= 0) return hipSuccess;
+  if (stats) return launch_pooled_t<512, true>(p, grid, stream);
+  switch (waves_per_wg) {
+  case 4: return launch_pooled_t<256, false>(p, grid, stream);
+  case 8: return launch_pooled_t<512, false>(p, grid, stream);
+  case 16: return launch_pooled_t<1024, false>(p, grid, stream);
   default: return hipErrorInvalidValue;
   }
 }

@@ -32,12 +32,16 @@ struct KParams {
   int lds_sph;           // sphere prefix staged in LDS
   int smax, lmax;        // per-lane LDS stack / deferred-leaf capacities
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
+  // pooled family
+  int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
 };
 
 hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream);
 // block = 64 * waves_per_wg threads (4, 8 or 16 waves); grid = persistent workgroups
 hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg);
+hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
+size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

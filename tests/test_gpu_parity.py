@@ -14,7 +14,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-VARIANTS = {"pixel": 1, "persistent": 2}
+VARIANTS = {"pixel": 1, "persistent": 2, "pooled": 3}
 
 
 @pytest.fixture(scope="module")
@@ -122,8 +122,9 @@ def test_big_scene_million_spheres(R, ctx):
     px = R.render(512, 512, ps)
     ref, _ = orc.render(512, 512)
     assert int((px != ref).sum()) == 0
-    ctx.set_variant(1)
-    assert int((R.render(512, 512, ps) != ref).sum()) == 0
+    for v in (1, 2, 3):
+        ctx.set_variant(v)
+        assert int((R.render(512, 512, ps) != ref).sum()) == 0, v
 
 
 def test_random_scene_with_duplicates_and_explicit_camera(R, ctx):
@@ -140,7 +141,7 @@ def test_random_scene_with_duplicates_and_explicit_camera(R, ctx):
     s[140:150] = s[40:50]                   # exact duplicates
     lf, la, fov = (5.0, 25.0, 70.0), (0.0, 0.0, 0.0), 60.0
     orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         ctx.set_variant(variant)
         ps = R.prepare_scene(150, 200, ctx.scene_from_spheres(s, lf, la, fov))
         got, want = ps.bvh_arrays(), orc.arrays()
@@ -173,9 +174,10 @@ def test_work_counters_match_oracle(R, ctx, scene, h):
     dict(thr_shade=64, thr_leaf=64), dict(lmax=2), dict(lmax=16), dict(lds_scene_bytes=0),
     dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192),
 ])
-def test_persistent_knobs_do_not_change_pixels(R, opts):
+@pytest.mark.parametrize("variant", [2, 3])
+def test_persistent_knobs_do_not_change_pixels(R, opts, variant):
     c = R.Context()
-    c.set_variant(2)
+    c.set_variant(variant)
     for k, v in opts.items():
         c.set_option(k, v)
     for scene in ("rgbbox", "irreg"):
@@ -185,14 +187,15 @@ def test_persistent_knobs_do_not_change_pixels(R, opts):
     c.close()
 
 
-def test_repeated_launches_share_the_ticket_counter(R, ctx):
-    """The persistent family's work queue is a monotonic counter that is never reset."""
-    ctx.set_variant(2)
+@pytest.mark.parametrize("variant", [2, 3])
+def test_repeated_launches_share_the_ticket_counter(R, ctx, variant):
+    """The persistent families' work queue is a monotonic counter that is never reset."""
+    ctx.set_variant(variant)
     ps_a = R.prepare_scene(64, 64, ctx.rgbbox())
     ps_b = R.prepare_scene(100, 36, ctx.irreg())
     wa, _ = _oracle("rgbbox").render(64, 64)
     wb, _ = _oracle("irreg").render(100, 36)
-    for _ in range(20):
+    for _ in range(10):
         assert (R.render(64, 64, ps_a) == wa).all()
         assert (R.render(100, 36, ps_b) == wb).all()
 

@@ -226,6 +226,173 @@ static bool wave_step(Wave &W, const SceneData &S, const Policy &P, unsigned &ne
   return true;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Pooled design: the wave owns 64 ray slots and two LDS work lists shared by all lanes --
+// a LIFO stack of (slot, inner node) items and a list of (slot, leaf) items.  Any lane
+// processes any item, so SIMT efficiency no longer depends on per-ray traversal lengths.
+// Per-slot completion is tracked by an outstanding-item counter; the closest hit by a
+// 64-bit min over (t bits << 32 | leaf index).
+// ---------------------------------------------------------------------------------------
+struct Slot {
+  Ray r{};
+  float lr = 1, lg = 1, lb = 1;
+  int depth = 0, pix = -1;
+  bool active = false;
+  unsigned long long key = 0;
+  int cnt = 0;
+};
+constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffu;  // (1e9, none)
+
+struct PWave {
+  Slot slot[64];
+  std::vector<unsigned> box, leaf;
+  unsigned q_next = 0, q_end = 0;
+  bool exhausted = false, done = false;
+};
+
+struct PCounters {
+  unsigned long long ops[3] = {0, 0, 0}, lanes[3] = {0, 0, 0};
+  unsigned long long rays = 0, box = 0, sphere = 0, fetches = 0;
+  size_t max_box = 0, max_leaf = 0;
+};
+
+static inline unsigned f2u(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float u2f(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, unsigned &next_ticket,
+                       std::vector<int32_t> &out, PCounters &C) {
+  const size_t nbox = W.box.size(), nleaf = W.leaf.size();
+  int op;
+  if (nbox >= (size_t)width) op = 0;
+  else if (nleaf >= (size_t)width) op = 1;
+  else {
+    int ndone = 0, nfree = 0;
+    for (auto &s : W.slot) {
+      if (s.active && s.cnt == 0) ndone++;
+      if (!s.active && !W.exhausted) nfree++;
+    }
+    if (ndone + nfree >= thr_shade || (nbox == 0 && nleaf == 0)) {
+      if (ndone + nfree == 0) { W.done = true; return false; }
+      op = 2;
+    } else if (nbox > 0) op = 0;
+    else op = 1;
+  }
+  C.ops[op]++;
+  if (op == 0) {
+    const size_t n = std::min(nbox, (size_t)width);
+    std::vector<unsigned> items(W.box.end() - n, W.box.end());
+    W.box.resize(nbox - n);
+    C.lanes[0] += n;
+    for (size_t k = 0; k < n; ++k) {
+      const unsigned it = items[n - 1 - k];
+      const int sl = it >> 26, ni = it & 0x3ffffff;
+      Slot &s = W.slot[sl];
+      const rt::TravNode &nd = S.nodes[ni];
+      C.box++;
+      if (box_hit(s.r, nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0], nd.hi[1], nd.hi[2])) {
+        const int kids[2] = {nd.left, nd.right};
+        for (int c : kids) {
+          if (c < 0) W.leaf.push_back(((unsigned)sl << 26) | (unsigned)~c);
+          else W.box.push_back(((unsigned)sl << 26) | (unsigned)c);
+        }
+        s.cnt += 1;
+      } else
+        s.cnt -= 1;
+    }
+    C.max_box = std::max(C.max_box, W.box.size());
+    C.max_leaf = std::max(C.max_leaf, W.leaf.size());
+  } else if (op == 1) {
+    const size_t n = std::min(nleaf, (size_t)width);
+    C.lanes[1] += n;
+    for (size_t k = 0; k < n; ++k) {
+      const unsigned it = W.leaf.back();
+      W.leaf.pop_back();
+      const int sl = it >> 26, j = it & 0x3ffffff;
+      Slot &s = W.slot[sl];
+      const F4 &sp = S.sph[j];
+      C.sphere++;
+      const float g = sphere_root(s.r, sp.x, sp.y, sp.z, sp.w);
+      if (g < kTMax) {
+        const unsigned long long key = ((unsigned long long)f2u(g) << 32) | (unsigned)j;
+        if (key < s.key) s.key = key;
+      }
+      s.cnt -= 1;
+    }
+  } else {
+    for (int l = 0; l < 64; ++l) {
+      Slot &s = W.slot[l];
+      if (s.active && s.cnt == 0) {
+        C.lanes[2]++;
+        const float best = u2f((unsigned)(s.key >> 32));
+        const int bestj = (s.key == kKeyInit) ? -1 : (int)(unsigned)(s.key & 0xffffffffu);
+        F4 sp{0, 0, 0, 1}, c{0, 0, 0, 0};
+        if (bestj >= 0) { sp = S.sph[bestj]; c = S.col[bestj]; }
+        int32_t pixel;
+        if (finish_ray(s.r, best, bestj, sp.x, sp.y, sp.z, sp.w, c.x, c.y, c.z, s.lr, s.lg, s.lb, s.depth, S.max_depth, &pixel)) {
+          s.key = kKeyInit; s.cnt = 1;
+          W.box.push_back(((unsigned)l << 26) | 0u);
+          C.rays++;
+        } else {
+          out[s.pix] = pixel;
+          s.active = false; s.pix = -1;
+        }
+      }
+    }
+    for (int l = 0; l < 64 && !W.exhausted; ++l) {
+      Slot &s = W.slot[l];
+      if (s.active) continue;
+      for (;;) {
+        if (W.q_next == W.q_end) {
+          const unsigned t = next_ticket++;
+          C.fetches++;
+          if (t >= (unsigned)S.nchunks) { W.exhausted = true; break; }
+          W.q_next = t * 64u; W.q_end = W.q_next + 64u;
+        }
+        const unsigned sidx = W.q_next++;
+        const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
+        const int tx = tile % S.tiles_x, ty = tile / S.tiles_x;
+        const int col = tx * 8 + (within & 7), row = ty * 8 + (within >> 3);
+        if (col < S.w && row < S.h) {
+          C.lanes[2]++;
+          s.r = primary_ray(S.cam, col, row, S.w, S.h);
+          s.lr = s.lg = s.lb = 1.0f; s.depth = 0; s.pix = row * S.w + col; s.active = true;
+          s.key = kKeyInit; s.cnt = 1;
+          W.box.push_back(((unsigned)l << 26) | 0u);
+          C.rays++;
+          break;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+static int run_pooled(const SceneData &S, const std::vector<int32_t> &ref, int nwaves, int width, int thr_shade) {
+  std::vector<int32_t> out(ref.size(), -1);
+  std::vector<PWave> waves(nwaves);
+  PCounters C;
+  unsigned next_ticket = 0;
+  bool any = true;
+  unsigned long long rounds = 0;
+  while (any) {
+    any = false;
+    for (auto &W : waves)
+      if (!W.done) any |= pwave_step(W, S, width, thr_shade, next_ticket, out, C);
+    rounds++;
+  }
+  size_t diff = 0;
+  for (size_t i = 0; i < ref.size(); ++i) diff += ref[i] != out[i];
+  std::printf("pooled(width %d, thr_shade %d, %d waves): checksum %08x diff_vs_simple %zu rays %llu box %llu sphere %llu fetches %llu\n",
+              width, thr_shade, nwaves, checksum(out), diff, C.rays, C.box, C.sphere, C.fetches);
+  const char *names[3] = {"BOX", "LEAF", "SHADE"};
+  for (int i = 0; i < 3; ++i)
+    std::printf("  %-5s wave-ops %10llu lanes %12llu efficiency %.3f\n", names[i], C.ops[i], C.lanes[i],
+                C.ops[i] ? (double)C.lanes[i] / ((i == 2 ? 64.0 : (double)width) * C.ops[i]) : 0.0);
+  std::printf("  rounds (longest wave, in phases) %llu  max box stack %zu  max leaf list %zu\n", rounds, C.max_box, C.max_leaf);
+  return diff ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s <rgbbox|irreg|floor:n:k> h w [thr_shade thr_leaf lmax nwaves policy max_depth]\n", argv[0]);
@@ -268,6 +435,10 @@ int main(int argc, char **argv) {
   std::printf("scene %s %dx%d spheres %lld height %d sweeps %d\n", name.c_str(), h, w, (long long)bvh.n, tl.height, bvh.sweeps);
   std::printf("simple: checksum %08x rays %llu box %llu sphere %llu\n", checksum(ref), C0.rays, C0.box, C0.sphere);
 
+  if (P.kind >= 10) {
+    // pooled design: kind 10 -> 64 items per op, kind 11 -> 128 items per op
+    return run_pooled(S, ref, nwaves, P.kind == 11 ? 128 : 64, P.thr_shade);
+  }
   std::vector<Wave> waves(nwaves);
   unsigned next_ticket = 0;
   bool any = true;
