@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 pixel kernel, 2 persistent kernel")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -178,10 +178,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
-                       "kernel": {0: "auto (persistent)", 1: "pixel", 2: "persistent"}[args.variant],
+                       "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
                        "options": opts, "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": f"persistent_kernel on {dscene} {dw}x{dh}" if args.variant != 1
-                         else f"pixel_kernel on {dscene} {dw}x{dh}",
+            "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
+                         + f" on {dscene} {dw}x{dh}",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
                          "note": "achieved = algorithmic bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) / mean "

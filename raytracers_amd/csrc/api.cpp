@@ -43,6 +43,12 @@ struct rt_context {
   unsigned *queue_dev = nullptr;
   unsigned queue_base = 0;
   unsigned long long *stats_dev = nullptr;
+  // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
+  struct UvTable {
+    int64_t w, h;
+    float *u, *v;
+  };
+  std::vector<UvTable> uv;
 };
 
 struct rt_scene {
@@ -83,6 +89,30 @@ int upload(rt_context *ctx, T **dev, const void *host, size_t bytes) {
   return 0;
 }
 
+// u/v tables for one image size (host computes the same correctly rounded divisions the
+// per-pixel code would: rtk::pixel_u / pixel_v), cached on the context.
+int get_uv(rt_context *ctx, int64_t w, int64_t h, const float **u, const float **v) {
+  for (const auto &t : ctx->uv)
+    if (t.w == w && t.h == h) { *u = t.u; *v = t.v; return 0; }
+  std::vector<float> hu(static_cast<size_t>(w)), hv(static_cast<size_t>(h));
+  for (int64_t i = 0; i < w; ++i) hu[i] = rtk::pixel_u(static_cast<int>(i), static_cast<int>(w));
+  for (int64_t j = 0; j < h; ++j) hv[j] = rtk::pixel_v(static_cast<int>(j), static_cast<int>(h));
+  rt_context::UvTable t{w, h, nullptr, nullptr};
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.u), hu.size() * 4));
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.v), hv.size() * 4));
+  RT_HIP(ctx, hipMemcpy(t.u, hu.data(), hu.size() * 4, hipMemcpyHostToDevice));
+  RT_HIP(ctx, hipMemcpy(t.v, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+  if (ctx->uv.size() >= 16) {   // small LRU-less cap: drop the oldest
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->uv.front().u);
+    (void)hipFree(ctx->uv.front().v);
+    ctx->uv.erase(ctx->uv.begin());
+  }
+  ctx->uv.push_back(t);
+  *u = t.u; *v = t.v;
+  return 0;
+}
+
 struct Plan {
   int variant;
   int lds_nodes, lds_sph, smax, lmax, waves, grid;
@@ -92,7 +122,8 @@ struct Plan {
 
 // Decide the launch shape of the persistent family for one prepared scene.
 int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
-  pl->variant = ctx->variant == RT_VARIANT_AUTO ? RT_VARIANT_PERSISTENT : ctx->variant;
+  pl->variant = ctx->variant;
+  if (pl->variant == RT_VARIANT_AUTO) pl->variant = ps->n < (int64_t(1) << 23) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
   if (pl->variant == RT_VARIANT_PIXEL) return 0;
   const int ni = static_cast<int>(ps->n - 1), n = static_cast<int>(ps->n);
   // depth-first with one node held in a register: at most one pending sibling per level
@@ -171,7 +202,11 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
-  if (pl.variant == RT_VARIANT_POOLED) RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+  if (pl.variant == RT_VARIANT_POOLED) {
+    if (ps->n >= (int64_t(1) << 23)) return fail(ctx, "pooled kernel: at most 2^23 spheres (work items carry 24-bit references)");
+    if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
+    RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+  }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
   ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
   return 0;
@@ -222,6 +257,10 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (auto &t : ctx->uv) {
+    (void)hipFree(t.u);
+    (void)hipFree(t.v);
+  }
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

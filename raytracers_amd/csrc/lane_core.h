@@ -53,9 +53,13 @@ RT_HD void ray_derive(Ray &r) {
 
 // trace_ray + get_ray (ray.fut:150-154, :109-114).  `col` = i, `row` = image row from
 // the top; the reference evaluates pixel (j = row) at v = (height - j) / height.
-RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
-  const float u = (float)col / (float)width;
-  const float v = (float)(height - row) / (float)height;
+RT_HD float pixel_u(int col, int width) { return (float)col / (float)width; }
+RT_HD float pixel_v(int row, int height) { return (float)(height - row) / (float)height; }
+
+// get_ray for precomputed (u, v): the pooled kernel reads u and v from per-column / per-row
+// tables the host fills with pixel_u / pixel_v (two correctly rounded divisions per pixel
+// become two loads; the values are the same bits).
+RT_HD Ray primary_ray_uv(const Cam &c, float u, float v) {
   Ray r;
   r.ox = c.ox; r.oy = c.oy; r.oz = c.oz;
   r.dx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
@@ -65,33 +69,43 @@ RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
   return r;
 }
 
-// aabb_hit (ray.fut:53-70) with tmin0 = 0, tmax0 = 1e9.  The reference exits early after
-// the x and y slabs; evaluating all three and AND-ing the verdicts is the same predicate.
+RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
+  const float u = pixel_u(col, width);
+  const float v = pixel_v(row, height);
+  Ray r;
+  r.ox = c.ox; r.oy = c.oy; r.oz = c.oz;
+  r.dx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
+  r.dy = ((c.ly + u * c.hy) + v * c.vy) - c.oy;
+  r.dz = ((c.lz + u * c.hz) + v * c.vz) - c.oz;
+  ray_derive(r);
+  return r;
+}
+
+// aabb_hit (ray.fut:53-70) with tmin0 = 0, tmax0 = 1e9.
+//
+// The reference tests `tmax_k <= tmin_k -> false` after each of the x, y, z slabs.  Only
+// the last test is evaluated here, which is the same predicate: fmax/fmin return the
+// non-NaN operand, so starting from the finite (0, 1e9) no tmin_k/tmax_k is ever NaN,
+// tmin_1 <= tmin_2 <= tmin_3 and tmax_1 >= tmax_2 >= tmax_3; hence tmax_3 > tmin_3 implies
+// tmax_k > tmin_k for k = 1, 2, and a failed earlier test implies tmax_3 <= tmin_3.
+// (The per-axis swap on `invD < 0` must stay a select: with a zero direction component,
+// 0 * inf = NaN bounds arise that min/max-based swapping would treat differently.)
+typedef float rt_f2 __attribute__((vector_size(8)));
 RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-  float tmin = 0.0f, tmax = kTMax;
-  bool ok;
-  {
-    const float t0 = (lox - r.ox) * r.ix, t1 = (hix - r.ox) * r.ix;
-    const bool neg = r.ix < 0.0f;
-    tmin = fmaxf(neg ? t1 : t0, tmin);
-    tmax = fminf(neg ? t0 : t1, tmax);
-    ok = !(tmax <= tmin);
-  }
-  {
-    const float t0 = (loy - r.oy) * r.iy, t1 = (hiy - r.oy) * r.iy;
-    const bool neg = r.iy < 0.0f;
-    tmin = fmaxf(neg ? t1 : t0, tmin);
-    tmax = fminf(neg ? t0 : t1, tmax);
-    ok = ok & !(tmax <= tmin);
-  }
-  {
-    const float t0 = (loz - r.oz) * r.iz, t1 = (hiz - r.oz) * r.iz;
-    const bool neg = r.iz < 0.0f;
-    tmin = fmaxf(neg ? t1 : t0, tmin);
-    tmax = fminf(neg ? t0 : t1, tmax);
-    ok = ok & !(tmax <= tmin);
-  }
-  return ok;
+  // x and y as a pair: two packed subtracts + two packed multiplies (v_pk_add/mul_f32 round
+  // each lane exactly like the scalar instructions)
+  const rt_f2 o2 = {r.ox, r.oy}, i2 = {r.ix, r.iy};
+  const rt_f2 lo2 = {lox, loy}, hi2 = {hix, hiy};
+  const rt_f2 t0 = (lo2 - o2) * i2, t1 = (hi2 - o2) * i2;
+  const float t0z = (loz - r.oz) * r.iz, t1z = (hiz - r.oz) * r.iz;
+  const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+  float tmin = fmaxf(nx ? t1[0] : t0[0], 0.0f);
+  float tmax = fminf(nx ? t0[0] : t1[0], kTMax);
+  tmin = fmaxf(ny ? t1[1] : t0[1], tmin);
+  tmax = fminf(ny ? t0[1] : t1[1], tmax);
+  tmin = fmaxf(nz ? t1z : t0z, tmin);
+  tmax = fminf(nz ? t0z : t1z, tmax);
+  return !(tmax <= tmin);
 }
 
 // The root closest_hit would accept for this sphere if its running t_max were large

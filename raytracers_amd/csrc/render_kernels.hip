@@ -293,7 +293,13 @@ __device__ __forceinline__ float pull(int lane_byte, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
 }
 
-template <int THREADS, bool STATS>
+// Work items are one dword: (reference << 8) | (slot * 4).  The low byte is the owning
+// lane's byte address for ds_bpermute and for the per-slot counter; `reference` is an inner
+// node index (box stack) or ~leaf index (leaf list), both < 2^23.
+//
+// ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
+// (buffer_load) path is compiled out.
+template <int THREADS, bool ALL_LDS, bool STATS>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -311,9 +317,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
 
   for (int i = threadIdx.x; i < 2 * p.lds_nodes; i += THREADS) smem[i] = p.nodes[i];
   for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) smem[sph_base + i] = p.sph[i];
-  wcnt[lane] = 0;
-  wkey[lane] = kKeyInit;
+  // Zero the work lists: lanes without an item read a stale entry and compute on it with
+  // their results masked off, so every stale entry must decode to valid indices.
+  for (int i = lane; i < per_wave_dw; i += 64) wbase[i] = 0u;
   __syncthreads();
+  wkey[lane] = kKeyInit;
 
   // ---- slot state, owned by this lane ----
   Ray r = {};
@@ -328,35 +336,133 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int op;   // 0 box, 1 leaf, 2 shade
-    if (nleaf >= 64) op = 1;
-    else if (nbox >= 64) op = 0;
-    else {
+    // both counters are wave-uniform by construction (ballot popcounts); pin them to SGPRs --
+    // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
+    nbox = __builtin_amdgcn_readfirstlane(nbox);
+    nleaf = __builtin_amdgcn_readfirstlane(nleaf);
+    if (nbox < 64 && nleaf < 64) {
+      // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
       const int ns = __popcll(__ballot(done | vacant));
-      if (ns >= p.thr_shade || (nbox == 0 && nleaf == 0)) {
+      if (ns >= p.thr_shade || (nbox | nleaf) == 0) {
         if (ns == 0) break;
-        op = 2;
-      } else op = nbox > 0 ? 0 : 1;
+        // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
+        bool root = false;
+        if (done) {
+          const unsigned long long key = wkey[lane];
+          const float best = __uint_as_float((unsigned)(key >> 32));
+          const int bestj = key == kKeyInit ? -1 : (int)(unsigned)(key & 0xffffffffull);
+          float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bestj >= 0) {
+            s = p.sph[bestj];
+            c = p.col[bestj];
+          }
+          int32_t pixel;
+          if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
+            root = true;
+          } else {
+            p.out[pix] = pixel;
+            pix = -1;
+          }
+        }
+        bool want = (pix < 0) & !exhausted;
+        int slot = -1;
+        unsigned long long m = __ballot(want);
+        while (m != 0ull) {            // wave-uniform loop
+          if (q_next == q_end) {
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= (unsigned)p.nchunks) {
+              exhausted = true;
+              break;
+            }
+            q_next = t * 64u;
+            q_end = q_next + 64u;
+          }
+          const unsigned avail = q_end - q_next;
+          const unsigned rank = (unsigned)lane_rank(m);
+          const unsigned cnt = (unsigned)__popcll(m);
+          if (want & (rank < avail)) {
+            const unsigned sidx = q_next + rank;
+            const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
+            const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+            const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+            if (col < p.w && lrow < p.rows_local) {
+              slot = lrow * p.w + col;
+              r = primary_ray_uv(p.cam, p.u_tab[col], p.v_tab[global_row(p, lrow)]);
+              want = false;
+            }
+          }
+          q_next += (cnt < avail) ? cnt : avail;
+          m = __ballot(want);
+        }
+        if (slot >= 0) {
+          lr = 1.0f; lg = 1.0f; lb = 1.0f;
+          depth = 0;
+          pix = slot;
+          root = true;
+        }
+        if (root) {
+          wkey[lane] = kKeyInit;
+          wcnt[lane] = 1;
+          if (STATS) n_rays++;
+        }
+        const unsigned long long m_root = __ballot(root);
+        if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
+        nbox += __popcll(m_root);
+        continue;
+      }
     }
-
-    if (op == 0) {
+    if (nleaf >= 64 || nbox == 0) {
+      // ---- LEAF: up to 64 (slot, sphere) items ----
+      const int top = nleaf - 1 - lane;
+      const unsigned item = wleaf[top < 0 ? 0 : top];
+      const bool act = top >= 0;
+      nleaf = nleaf > 64 ? nleaf - 64 : 0;
+      const int sl4 = (int)(item & 0xfcu);
+      const int j = ~((int)item >> 8);        // stale zero entry -> ~0 = -1: masked below
+      Ray q;
+      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
+      q.dx = pull(sl4, r.dx); q.dy = pull(sl4, r.dy); q.dz = pull(sl4, r.dz);
+      q.a = pull(sl4, r.a);
+      const int jj = act ? j : 0;
+      float4 s;
+      if (ALL_LDS) {
+        s = smem[sph_base + jj];
+      } else {
+        s = smem[sph_base + (jj < p.lds_sph ? jj : 0)];
+        if (jj >= p.lds_sph) s = buf_load16(rs_sph, jj * 16);
+      }
+      if (STATS) n_sph += act ? 1 : 0;
+      const float g = sphere_root(q, s.x, s.y, s.z, s.w);
+      if (act & (g < kTMax))
+        atomicMin(&wkey[sl4 >> 2], ((unsigned long long)__float_as_uint(g) << 32) | (unsigned)jj);
+      if (act) atomicAdd(&wcnt[sl4 >> 2], -1);
+    } else {
       // ---- BOX: up to 64 (slot, node) items ----
-      const int n = nbox < 64 ? nbox : 64;
-      const bool act = lane < n;
-      const unsigned item = wbox[act ? nbox - 1 - lane : 0];
-      nbox -= n;
-      const int sl4 = act ? (int)(item >> 26) * 4 : lane * 4;
-      const int ni = act ? (int)(item & 0x3ffffffu) : 0;
+      const int top = nbox - 1 - lane;
+      const unsigned item = wbox[top < 0 ? 0 : top];
+      const bool act = top >= 0;
+      nbox = nbox > 64 ? nbox - 64 : 0;
+      const int sl4 = (int)(item & 0xfcu);
+      const int ni = (int)(item >> 8);
       Ray q;
       q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
       q.ix = pull(sl4, r.ix); q.iy = pull(sl4, r.iy); q.iz = pull(sl4, r.iz);
-      const int li = ni < p.lds_nodes ? ni : 0;
-      float4 lo = smem[2 * li], hi = smem[2 * li + 1];
-      if (ni >= p.lds_nodes) {
-        lo = buf_load16(rs_nodes, ni * 32);
-        hi = buf_load16(rs_nodes, ni * 32 + 16);
+      float4 lo, hi;
+      if (ALL_LDS) {
+        lo = smem[2 * ni];
+        hi = smem[2 * ni + 1];
+      } else {
+        const int li = ni < p.lds_nodes ? ni : 0;
+        lo = smem[2 * li];
+        hi = smem[2 * li + 1];
+        if (ni >= p.lds_nodes) {
+          lo = buf_load16(rs_nodes, ni * 32);
+          hi = buf_load16(rs_nodes, ni * 32 + 16);
+        }
       }
       const int cl = f2i(lo.w), cr = f2i(hi.w);
       const bool hit = act & box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
@@ -365,103 +471,16 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const bool lfl = hit & (cl < 0), lfr = hit & (cr < 0);
       const unsigned long long m_inl = __ballot(inl), m_inr = __ballot(inr);
       const unsigned long long m_lfl = __ballot(lfl), m_lfr = __ballot(lfr);
-      const unsigned tag = item & 0xfc000000u;
-      const int pin = nbox + lane_rank(m_inl) + lane_rank(m_inr);
-      if (inl) wbox[pin] = tag | (unsigned)cl;
-      if (inr) wbox[pin + (inl ? 1 : 0)] = tag | (unsigned)cr;
-      nbox += __popcll(m_inl) + __popcll(m_inr);
-      const int plf = nleaf + lane_rank(m_lfl) + lane_rank(m_lfr);
-      if (lfl) wleaf[plf] = tag | (unsigned)~cl;
-      if (lfr) wleaf[plf + (lfl ? 1 : 0)] = tag | (unsigned)~cr;
-      nleaf += __popcll(m_lfl) + __popcll(m_lfr);
+      // left children first, then right children (two independent prefix ranks)
+      const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
+      if (inl) wbox[nbox + lane_rank(m_inl)] = ((unsigned)cl << 8) | (unsigned)sl4;
+      if (inr) wbox[nbox + c_inl + lane_rank(m_inr)] = ((unsigned)cr << 8) | (unsigned)sl4;
+      nbox += c_inl + __popcll(m_inr);
+      if (lfl) wleaf[nleaf + lane_rank(m_lfl)] = ((unsigned)cl << 8) | (unsigned)sl4;
+      if (lfr) wleaf[nleaf + c_lfl + lane_rank(m_lfr)] = ((unsigned)cr << 8) | (unsigned)sl4;
+      nleaf += c_lfl + __popcll(m_lfr);
       // one item consumed, two created on a hit: outstanding += hit ? +1 : -1
       if (act) atomicAdd(&wcnt[sl4 >> 2], hit ? 1 : -1);
-    } else if (op == 1) {
-      // ---- LEAF: up to 64 (slot, sphere) items ----
-      const int n = nleaf < 64 ? nleaf : 64;
-      const bool act = lane < n;
-      const unsigned item = wleaf[act ? nleaf - 1 - lane : 0];
-      nleaf -= n;
-      const int sl4 = act ? (int)(item >> 26) * 4 : lane * 4;
-      const int j = act ? (int)(item & 0x3ffffffu) : 0;
-      Ray q;
-      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
-      q.dx = pull(sl4, r.dx); q.dy = pull(sl4, r.dy); q.dz = pull(sl4, r.dz);
-      q.a = pull(sl4, r.a);
-      float4 s = smem[sph_base + (j < p.lds_sph ? j : 0)];
-      if (j >= p.lds_sph) s = buf_load16(rs_sph, j * 16);
-      if (STATS) n_sph += act ? 1 : 0;
-      const float g = sphere_root(q, s.x, s.y, s.z, s.w);
-      if (act & (g < kTMax))
-        atomicMin(&wkey[sl4 >> 2], ((unsigned long long)__float_as_uint(g) << 32) | (unsigned)j);
-      if (act) atomicAdd(&wcnt[sl4 >> 2], -1);
-    } else {
-      // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
-      bool root = false;
-      if ((pix >= 0) & (wcnt[lane] == 0)) {
-        const unsigned long long key = wkey[lane];
-        const float best = __uint_as_float((unsigned)(key >> 32));
-        const int bestj = key == kKeyInit ? -1 : (int)(unsigned)(key & 0xffffffffull);
-        float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bestj >= 0) {
-          s = p.sph[bestj];
-          c = p.col[bestj];
-        }
-        int32_t pixel;
-        if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
-          root = true;
-        } else {
-          p.out[pix] = pixel;
-          pix = -1;
-        }
-      }
-      bool want = (pix < 0) & !exhausted;
-      int slot = -1;
-      unsigned long long m = __ballot(want);
-      while (m != 0ull) {            // wave-uniform loop
-        if (q_next == q_end) {
-          unsigned t = 0;
-          if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
-          t = __builtin_amdgcn_readfirstlane(t);
-          if (t >= (unsigned)p.nchunks) {
-            exhausted = true;
-            break;
-          }
-          q_next = t * 64u;
-          q_end = q_next + 64u;
-        }
-        const unsigned avail = q_end - q_next;
-        const unsigned rank = (unsigned)lane_rank(m);
-        const unsigned cnt = (unsigned)__popcll(m);
-        if (want & (rank < avail)) {
-          const unsigned sidx = q_next + rank;
-          const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
-          const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-          const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
-          if (col < p.w && lrow < p.rows_local) {
-            slot = lrow * p.w + col;
-            want = false;
-          }
-        }
-        q_next += (cnt < avail) ? cnt : avail;
-        m = __ballot(want);
-      }
-      if (slot >= 0) {
-        const int lrow = slot / p.w, col = slot - lrow * p.w;
-        r = primary_ray(p.cam, col, global_row(p, lrow), p.w, p.h);
-        lr = 1.0f; lg = 1.0f; lb = 1.0f;
-        depth = 0;
-        pix = slot;
-        root = true;
-      }
-      if (root) {
-        wkey[lane] = kKeyInit;
-        wcnt[lane] = 1;
-        if (STATS) n_rays++;
-      }
-      const unsigned long long m_root = __ballot(root);
-      if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 26;   // (slot = lane, node 0)
-      nbox += __popcll(m_root);
     }
   }
   if (STATS) {
@@ -531,10 +550,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int wave
   return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (192 + capb + capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool STATS>
+template <int THREADS, bool ALL_LDS, bool STATS>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, STATS>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -548,11 +567,12 @@ static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream
 
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
-  if (stats) return launch_pooled_t<512, true>(p, grid, stream);
+  const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
+  if (stats) return launch_pooled_t<512, false, true>(p, grid, stream);
   switch (waves_per_wg) {
-  case 4: return launch_pooled_t<256, false>(p, grid, stream);
-  case 8: return launch_pooled_t<512, false>(p, grid, stream);
-  case 16: return launch_pooled_t<1024, false>(p, grid, stream);
+  case 4: return all_lds ? launch_pooled_t<256, true, false>(p, grid, stream) : launch_pooled_t<256, false, false>(p, grid, stream);
+  case 8: return all_lds ? launch_pooled_t<512, true, false>(p, grid, stream) : launch_pooled_t<512, false, false>(p, grid, stream);
+  case 16: return all_lds ? launch_pooled_t<1024, true, false>(p, grid, stream) : launch_pooled_t<1024, false, false>(p, grid, stream);
   default: return hipErrorInvalidValue;
   }
 }

@@ -34,6 +34,8 @@ struct KParams {
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
+  const float *u_tab;    // [w]  pixel_u(col, w)
+  const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
 };
 
 hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream);
