@@ -37,6 +37,7 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
   // wave stops at its first out-of-range ticket), so the next launch's base is known.
@@ -55,7 +56,19 @@ struct rt_scene {
   rt::SceneDesc desc;
 };
 
+// Tile-order state of one (image size, partition, depth, camera) view of a prepared scene.
+struct TileOrder {
+  int64_t h, w;
+  int32_t rows_per_tile, part, nparts, max_depth;
+  float cam[12];
+  int ntiles = 0;
+  int *cost = nullptr;    // [ntiles] record written by the render kernel
+  int *order = nullptr;   // [ntiles] ticket -> tile table for the next frame
+  bool valid = false;     // order[] has been computed from a previous frame
+};
+
 struct rt_prepared {
+  mutable std::vector<TileOrder> orders;
   int64_t n = 0;
   int64_t h = 0, w = 0;
   rt::Camera cam{};
@@ -205,7 +218,38 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 23)) return fail(ctx, "pooled kernel: at most 2^23 spheres (work items carry 24-bit references)");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
+    TileOrder *to = nullptr;
+    if (ctx->adaptive_order) {
+      for (auto &o : ps->orders)
+        if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
+            o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks)
+          to = &o;
+      if (!to) {
+        if (ps->orders.size() >= 8) {   // bounded: forget the oldest view
+          (void)hipStreamSynchronize(ctx->stream);
+          (void)hipFree(ps->orders.front().cost);
+          (void)hipFree(ps->orders.front().order);
+          ps->orders.erase(ps->orders.begin());
+        }
+        TileOrder o{};
+        o.h = h; o.w = w; o.rows_per_tile = rows_per_tile; o.part = part; o.nparts = nparts; o.max_depth = max_depth;
+        std::memcpy(o.cam, &p.cam, sizeof o.cam);
+        o.ntiles = p.nchunks;
+        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
+        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(o.ntiles)));
+        RT_HIP(ctx, hipMemsetAsync(o.cost, 0, sizeof(int) * static_cast<size_t>(o.ntiles), ctx->stream));
+        ps->orders.push_back(o);
+        to = &ps->orders.back();
+      }
+      p.cost = to->cost;
+      p.order = to->valid ? to->order : nullptr;
+    }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+    if (to) {
+      // next frame's ticket -> tile table from this frame's record (also clears the record)
+      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, ctx->stream));
+      to->valid = true;
+    }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
   ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
@@ -303,6 +347,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_scene_bytes = v;
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
+  } else if (k == "adaptive_order") {
+    ctx->adaptive_order = v != 0;
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -398,6 +444,10 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
                   static_cast<void *>(ps->left), static_cast<void *>(ps->right), static_cast<void *>(ps->parent),
                   static_cast<void *>(ps->nodes), static_cast<void *>(ps->sph), static_cast<void *>(ps->col)})
     if (p) (void)hipFree(p);
+  for (auto &o : ps->orders) {
+    (void)hipFree(o.cost);
+    (void)hipFree(o.order);
+  }
   delete ps;
   return 0;
 }

@@ -105,6 +105,10 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
 // ---------------------------------------------------------------------------------
 // Family 2: persistent waves.
 // ---------------------------------------------------------------------------------
+// ballot of a bool: the v_cmp result IS the 64-bit lane mask (HIP's __ballot(int) would go
+// bool -> int -> compare again)
+__device__ __forceinline__ unsigned long long bal(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 __device__ __forceinline__ int lane_rank(unsigned long long m) {   // # set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
     const bool can_leaf = nl > 0;
     const bool idle = !has_node & (nl == 0);
     const bool want_shade = idle & ((pix >= 0) | !exhausted);
-    const unsigned long long mb = __ballot(can_box), ml = __ballot(can_leaf), ms = __ballot(want_shade);
+    const unsigned long long mb = bal(can_box), ml = bal(can_leaf), ms = bal(want_shade);
     if ((mb | ml | ms) == 0ull) break;
     const int nb = __popcll(mb), nlv = __popcll(ml), ns = __popcll(ms);
 
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
       }
       bool want = idle & (pix < 0) & !exhausted;
       int slot = -1;                 // tile-queue slot assigned to this lane
-      unsigned long long m = __ballot(want);
+      unsigned long long m = bal(want);
       while (m != 0ull) {            // wave-uniform loop
         if (q_next == q_end) {
           unsigned t = 0;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
           }
         }
         q_next += (cnt < avail) ? cnt : avail;
-        m = __ballot(want);
+        m = bal(want);
       }
       if (slot >= 0) {
         const int lrow = slot / p.w, col = slot - lrow * p.w;
@@ -332,6 +336,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // ---- wave state (uniform) ----
   int nbox = 0, nleaf = 0;
   unsigned q_next = 0, q_end = 0;
+  int q_tile = 0;          // tile the current ticket maps to
+  int ptile = 0;           // (per lane) tile of the pixel in this slot, for the cost record
   bool exhausted = false;
 
   for (;;) {
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
-      const int ns = __popcll(__ballot(done | vacant));
+      const int ns = __popcll(bal(done | vacant));
       if (ns >= p.thr_shade || (nbox | nleaf) == 0) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
@@ -364,11 +370,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           } else {
             p.out[pix] = pixel;
             pix = -1;
+            // cost record for the adaptive tile order: the longest bounce chain seen in the tile
+            if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
           }
         }
         bool want = (pix < 0) & !exhausted;
         int slot = -1;
-        unsigned long long m = __ballot(want);
+        unsigned long long m = bal(want);
         while (m != 0ull) {            // wave-uniform loop
           if (q_next == q_end) {
             unsigned t = 0;
@@ -380,23 +388,24 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             }
             q_next = t * 64u;
             q_end = q_next + 64u;
+            q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
           }
           const unsigned avail = q_end - q_next;
           const unsigned rank = (unsigned)lane_rank(m);
           const unsigned cnt = (unsigned)__popcll(m);
           if (want & (rank < avail)) {
-            const unsigned sidx = q_next + rank;
-            const int tile = (int)(sidx >> 6), within = (int)(sidx & 63u);
-            const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+            const int within = (int)((q_next + rank) & 63u);
+            const int tx = q_tile % p.tiles_x, ty = q_tile / p.tiles_x;
             const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
             if (col < p.w && lrow < p.rows_local) {
               slot = lrow * p.w + col;
+              ptile = q_tile;
               r = primary_ray_uv(p.cam, p.u_tab[col], p.v_tab[global_row(p, lrow)]);
               want = false;
             }
           }
           q_next += (cnt < avail) ? cnt : avail;
-          m = __ballot(want);
+          m = bal(want);
         }
         if (slot >= 0) {
           lr = 1.0f; lg = 1.0f; lb = 1.0f;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           wcnt[lane] = 1;
           if (STATS) n_rays++;
         }
-        const unsigned long long m_root = __ballot(root);
+        const unsigned long long m_root = bal(root);
         if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
         nbox += __popcll(m_root);
         continue;
@@ -465,12 +474,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         }
       }
       const int cl = f2i(lo.w), cr = f2i(hi.w);
-      const bool hit = act & box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+      const bool hit = act && box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
       if (STATS) n_box += act ? 1 : 0;
-      const bool inl = hit & (cl >= 0), inr = hit & (cr >= 0);
-      const bool lfl = hit & (cl < 0), lfr = hit & (cr < 0);
-      const unsigned long long m_inl = __ballot(inl), m_inr = __ballot(inr);
-      const unsigned long long m_lfl = __ballot(lfl), m_lfr = __ballot(lfr);
+      const bool lneg = cl < 0, rneg = cr < 0;
+      const bool inl = hit && !lneg, inr = hit && !rneg;
+      const bool lfl = hit && lneg, lfr = hit && rneg;
+      const unsigned long long m_inl = bal(inl), m_inr = bal(inr);
+      const unsigned long long m_lfl = bal(lfl), m_lfr = bal(lfr);
       // left children first, then right children (two independent prefix ranks)
       const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
       if (inl) wbox[nbox + lane_rank(m_inl)] = ((unsigned)cl << 8) | (unsigned)sl4;
@@ -488,6 +498,74 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     atomicAdd(&p.stats[1], n_box);
     atomicAdd(&p.stats[2], n_sph);
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Adaptive tile order.  The frame time at 1000x1000 is bounded below by the longest bounce
+// chain (a 50-bounce pixel is ~50 x (tree height + 3) dependent wave operations), so chains
+// must START early.  Every frame records per tile the longest chain it saw (p.cost); this
+// kernel turns the record into the ticket -> tile table of the NEXT frame of the same
+// prepared scene: a stable counting sort by cost class (floor(log2), descending), and clears
+// the record.  It only permutes the order in which independent pixels are traced.
+// ---------------------------------------------------------------------------------
+constexpr int kOrderThreads = 1024;
+constexpr int kOrderClasses = 8;
+
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles) {
+  __shared__ int hist[kOrderClasses][kOrderThreads];   // [class][thread], 32 KB
+  __shared__ int class_base[kOrderClasses + 1];
+  const int t = threadIdx.x;
+  const int per = (ntiles + kOrderThreads - 1) / kOrderThreads;
+  const int begin = t * per, end = min(ntiles, begin + per);
+  int local[kOrderClasses];
+#pragma unroll
+  for (int c = 0; c < kOrderClasses; ++c) local[c] = 0;
+  for (int i = begin; i < end; ++i) {
+    const int v = cost[i];
+    const int cls = kOrderClasses - 1 - min(kOrderClasses - 1, v > 0 ? 31 - __clz(v) : 0);   // 0 = most expensive
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) local[c] += (c == cls) ? 1 : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < kOrderClasses; ++c) hist[c][t] = local[c];
+  __syncthreads();
+  // exclusive scan of each class row across threads (one wave-free serial pass per class by 8 threads
+  // would be slow: 1024 entries; use a simple Hillis-Steele in place)
+  for (int off = 1; off < kOrderThreads; off <<= 1) {
+    int add[kOrderClasses];
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) add[c] = t >= off ? hist[c][t - off] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) hist[c][t] += add[c];
+    __syncthreads();
+  }
+  if (t == 0) {
+    int acc = 0;
+    for (int c = 0; c < kOrderClasses; ++c) {
+      class_base[c] = acc;
+      acc += hist[c][kOrderThreads - 1];
+    }
+    class_base[kOrderClasses] = acc;
+  }
+  __syncthreads();
+  int pos[kOrderClasses];
+#pragma unroll
+  for (int c = 0; c < kOrderClasses; ++c) pos[c] = class_base[c] + hist[c][t] - local[c];   // inclusive -> exclusive
+  for (int i = begin; i < end; ++i) {
+    const int v = cost[i];
+    const int cls = kOrderClasses - 1 - min(kOrderClasses - 1, v > 0 ? 31 - __clz(v) : 0);
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c)
+      if (c == cls) order[pos[c]++] = i;
+    cost[i] = 0;
+  }
+}
+
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream) {
+  if (ntiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, ntiles);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------

@@ -34,6 +34,8 @@ struct KParams {
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
+  const int *order;      // [nchunks] ticket -> tile (nullptr: identity)
+  int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
 };
@@ -44,6 +46,7 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg);
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
 size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg);
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 
