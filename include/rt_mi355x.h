@@ -102,6 +102,12 @@ int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, 
 int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                     uint64_t stats3[3]);
 
+/* Diagnostic: one instrumented launch of the pooled kernel; per wave 8 x u64 = {clock at start,
+ * at queue exhaustion, at exit, #BOX ops, #LEAF ops, #SHADE ops, (box items << 32 | leaf items),
+ * deepest bounce chain finished}. */
+int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                    uint64_t *records, int32_t max_waves, int32_t *num_waves);
+
 /* Times `iters` back-to-back launches of rt_render_part with HIP events recorded on the
  * context's stream (after `warmup` untimed launches); ms_out[i] = duration of launch i. */
 int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,

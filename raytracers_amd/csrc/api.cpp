@@ -37,6 +37,7 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
@@ -215,6 +216,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
+  p.prio_depth = ctx->prio_depth;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 23)) return fail(ctx, "pooled kernel: at most 2^23 spheres (work items carry 24-bit references)");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
@@ -245,8 +247,9 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
       p.order = to->valid ? to->order : nullptr;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
-    if (to) {
-      // next frame's ticket -> tile table from this frame's record (also clears the record)
+    if (to && (!to->valid || ctx->adaptive_order == 1)) {
+      // next frame's ticket -> tile table from this frame's record (also clears the record);
+      // adaptive_order == 2 computes the table once per view and then keeps it
       RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, ctx->stream));
       to->valid = true;
     }
@@ -347,8 +350,10 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_scene_bytes = v;
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
+  } else if (k == "prio_depth") {
+    ctx->prio_depth = std::max(0, v);
   } else if (k == "adaptive_order") {
-    ctx->adaptive_order = v != 0;
+    ctx->adaptive_order = v;
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -520,6 +525,67 @@ extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(ctx, e, "rt_render_stats");
   for (int i = 0; i < 3; ++i) stats3[i] = host[i];
+  return 0;
+}
+
+// Diagnostic: one instrumented pooled launch that records, per wave, clock64 at start / at
+// queue exhaustion / at exit, the number of BOX / LEAF / SHADE operations, the items they
+// processed ((box << 32) | leaf) and the deepest bounce chain finished.  records: waves x 8 u64.
+extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
+                               uint64_t *records, int32_t max_waves, int32_t *num_waves) {
+  if (!ctx || !ps || !records || !num_waves) return fail(ctx, "null argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  Plan pl{};
+  const int saved = ctx->variant;
+  ctx->variant = RT_VARIANT_POOLED;
+  int rc = make_plan(ctx, ps, &pl);
+  ctx->variant = saved;
+  if (rc) return rc;
+  pl.waves = 8;   // the instrumented instantiation is the 512-thread one
+  rc = 0;
+  const int nw = pl.grid * pl.waves;
+  if (nw > max_waves) return fail(ctx, "trace buffer too small");
+  int32_t *tmp = nullptr;
+  unsigned long long *trace = nullptr;
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(int32_t) * static_cast<size_t>(h) * w));
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * 8 * static_cast<size_t>(nw)));
+  RT_HIP(ctx, hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), ctx->stream));
+  rtk::KParams p{};
+  p.nodes = ps->nodes; p.sph = ps->sph; p.col = ps->col;
+  p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
+  std::memcpy(&p.cam, &ps->cam, sizeof(p.cam));
+  p.w = static_cast<int>(w); p.h = static_cast<int>(h);
+  p.rows_local = p.h; p.rows_per_tile = 8; p.part = 0; p.nparts = 1;
+  p.tiles_x = (p.w + 7) / 8;
+  p.max_depth = max_depth;
+  p.out = tmp;
+  p.stats = ctx->stats_dev;
+  p.trace = trace;
+  p.queue = ctx->queue_dev; p.queue_base = ctx->queue_base;
+  p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
+  p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
+  p.smax = pl.smax; p.lmax = pl.lmax;
+  p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
+  p.capb = pl.capb; p.capl = pl.capl;
+  p.prio_depth = ctx->prio_depth;
+  hipError_t e = hipSuccess;
+  if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
+  if (!rc) {
+    // use the adaptive order of the matching view if one exists (read-only here)
+    for (auto &o : ps->orders)
+      if (o.h == h && o.w == w && o.part == 0 && o.nparts == 1 && o.max_depth == max_depth && o.valid &&
+          ctx->adaptive_order && o.ntiles == p.nchunks)
+        p.order = o.order;
+    e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
+    ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(nw);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(tmp);
+  (void)hipFree(trace);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(ctx, e, "rt_render_trace");
+  *num_waves = nw;
   return 0;
 }
 

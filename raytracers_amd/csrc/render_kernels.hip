@@ -339,6 +339,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int q_tile = 0;          // tile the current ticket maps to
   int ptile = 0;           // (per lane) tile of the pixel in this slot, for the cost record
   bool exhausted = false;
+  // instrumented build only: per-wave timeline (rt_render_trace)
+  unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
+  int tr_maxdepth = 0;
+  if (STATS) tr_t0 = clock64();
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -355,7 +359,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
+        if (STATS) tr_ops[2]++;
         if (done) {
+          if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
           const unsigned long long key = wkey[lane];
           const float best = __uint_as_float((unsigned)(key >> 32));
           const int bestj = key == kKeyInit ? -1 : (int)(unsigned)(key & 0xffffffffull);
@@ -384,6 +390,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= (unsigned)p.nchunks) {
               exhausted = true;
+              if (STATS) tr_exh = clock64();
               break;
             }
             q_next = t * 64u;
@@ -421,11 +428,22 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const unsigned long long m_root = bal(root);
         if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
         nbox += __popcll(m_root);
+        // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
+        // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
+        // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
+        if (p.prio_depth > 0) {
+          const bool live = pix >= 0;
+          if (bal(live && depth >= 4 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(3);
+          else if (bal(live && depth >= 2 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(2);
+          else if (bal(live && depth >= p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
         continue;
       }
     }
     if (nleaf >= 64 || nbox == 0) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
+      if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;
       const unsigned item = wleaf[top < 0 ? 0 : top];
       const bool act = top >= 0;
@@ -451,6 +469,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       if (act) atomicAdd(&wcnt[sl4 >> 2], -1);
     } else {
       // ---- BOX: up to 64 (slot, node) items ----
+      if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
       const int top = nbox - 1 - lane;
       const unsigned item = wbox[top < 0 ? 0 : top];
       const bool act = top >= 0;
@@ -497,6 +516,17 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     atomicAdd(&p.stats[0], n_rays);
     atomicAdd(&p.stats[1], n_box);
     atomicAdd(&p.stats[2], n_sph);
+    if (p.trace != nullptr) {
+      const unsigned long long t_end = clock64();
+      int md = tr_maxdepth;
+      for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(md, o); md = other > md ? other : md; }
+      if (lane == 0) {
+        unsigned long long *rec = p.trace + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
+        rec[0] = tr_t0; rec[1] = tr_exh; rec[2] = t_end;
+        rec[3] = tr_ops[0]; rec[4] = tr_ops[1]; rec[5] = tr_ops[2];
+        rec[6] = (tr_items[0] << 32) | tr_items[1]; rec[7] = (unsigned long long)md;
+      }
+    }
   }
 }
 

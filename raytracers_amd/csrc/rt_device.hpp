@@ -24,6 +24,7 @@ struct KParams {
   int max_depth;
   int32_t *out;          // [rows_local * w]
   unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
+  unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
   // persistent family
   unsigned *queue;       // monotonic ticket counter (never reset; see Context::queue_base)
   unsigned queue_base;   // counter value at which this launch's ticket 0 sits
@@ -34,6 +35,7 @@ struct KParams {
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
+  int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [nchunks] ticket -> tile (nullptr: identity)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)

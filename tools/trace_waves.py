@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the pooled kernel (rt_render_trace): where does the frame time go?
+usage: trace_waves.py scene h w [opt=value ...]"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import raytracers_amd as R
+from raytracers_amd._lib import lib
+
+scene, h, w = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+ctx = R.Context()
+ctx.set_variant(3)
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
+ps = R.prepare_scene(h, w, ctx.scene(scene))
+for _ in range(3):   # warm up + let the adaptive order settle
+    R.render(h, w, ps)
+rec = np.zeros((8192, 8), dtype=np.uint64)
+n = C.c_int32()
+ctx._check(lib.rt_render_trace(ctx._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
+rec = rec[: n.value].astype(np.int64)
+t0 = rec[:, 0].min()
+start, exh, end = rec[:, 0] - t0, rec[:, 1] - t0, rec[:, 2] - t0
+exh = np.where(rec[:, 1] > 0, exh, end)
+print(f"{scene} {w}x{h}: {n.value} waves; kernel span {end.max()} clk")
+for name, v in (("start", start), ("queue exhausted", exh), ("end", end)):
+    print(f"  {name:16s} min {v.min():9d}  p50 {int(np.median(v)):9d}  p90 {int(np.percentile(v, 90)):9d}  max {v.max():9d}")
+life = end - start
+print(f"  mean wave lifetime {life.mean():.0f} clk = {life.mean() / end.max():.2f} of the span")
+ops = rec[:, 3:6]
+items_box, items_leaf = rec[:, 6] >> 32, rec[:, 6] & 0xFFFFFFFF
+tot = ops.sum(axis=1)
+print(f"  ops/wave: mean {tot.mean():.0f} max {tot.max()}  (BOX {ops[:,0].sum()} LEAF {ops[:,1].sum()} SHADE {ops[:,2].sum()})")
+print(f"  lane efficiency: BOX {items_box.sum() / (64.0 * ops[:,0].sum()):.3f} LEAF {items_leaf.sum() / (64.0 * ops[:,1].sum()):.3f}")
+print(f"  clk per op (lifetime / ops): mean {(life / np.maximum(tot, 1)).mean():.0f}")
+late = np.argsort(end)[-8:]
+for i in late[::-1]:
+    print(f"    wave {i:5d}: end {end[i]:9d} exhausted {exh[i]:9d} ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}"
+          f" drain clk/op {(end[i]-exh[i]) / max(1, 1):.0f}")
+# drain phase: ops after exhaustion are unknown per wave, but the time is:
+print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.0f} max {np.max(end - exh)} clk")

@@ -30,6 +30,7 @@ struct SceneData {
   std::vector<F4> sph, col;
   Cam cam;
   int w, h, tiles_x, nchunks, max_depth;
+  unsigned long long *depth_hist = nullptr;   // [64] pixels by number of scatters
 };
 
 struct Lane {
@@ -91,6 +92,10 @@ static void render_simple(const SceneData &S, std::vector<int32_t> &out, Counter
         if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, S.max_depth, &pixel)) break;
       }
       out[(size_t)row * S.w + col] = pixel;
+      if (S.depth_hist) {
+#pragma omp atomic
+        S.depth_hist[depth < 63 ? depth : 63]++;
+      }
     }
   C.rays = rays; C.box = box; C.sphere = sph;
 }
@@ -431,7 +436,13 @@ int main(int argc, char **argv) {
 
   std::vector<int32_t> ref((size_t)h * w, -1), out((size_t)h * w, -1);
   Counters C0, C;
+  unsigned long long dh[64] = {0};
+  S.depth_hist = dh;
   render_simple(S, ref, C0);
+  S.depth_hist = nullptr;
+  std::printf("pixels by bounce count (scatters):");
+  for (int d = 0; d < 64; ++d) if (dh[d]) std::printf(" %d:%llu", d, dh[d]);
+  std::printf("\n");
   std::printf("scene %s %dx%d spheres %lld height %d sweeps %d\n", name.c_str(), h, w, (long long)bvh.n, tl.height, bvh.sweeps);
   std::printf("simple: checksum %08x rays %llu box %llu sphere %llu\n", checksum(ref), C0.rays, C0.box, C0.sphere);
 
