@@ -78,7 +78,8 @@ struct rt_prepared {
   float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
   int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
   // traversal copy
-  float4 *nodes = nullptr, *sph = nullptr, *col = nullptr;
+  float4 *nodes = nullptr, *nodes64 = nullptr, *sph = nullptr, *col = nullptr;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
 };
 
 namespace {
@@ -153,18 +154,19 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
   pl->capb = 64 * (ps->height + 3);
   pl->capl = 256;
-  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (192 + pl->capb + pl->capl) * 4
+  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl) * 4
                                                        : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
   int budget = total - scratch - 512;
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   if (budget < 0) return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
   int ln, ls;
+  const int node_bytes = pl->variant == RT_VARIANT_POOLED ? 64 : 32;
   if (ctx->lds_sph_first) {
     ls = std::min(n, budget / 16);
-    ln = std::min(ni, (budget - ls * 16) / 32);
+    ln = std::min(ni, (budget - ls * 16) / node_bytes);
   } else {
-    ln = std::min(ni, budget / 32);
-    ls = std::min(n, (budget - ln * 32) / 16);
+    ln = std::min(ni, budget / node_bytes);
+    ls = std::min(n, (budget - ln * node_bytes) / 16);
   }
   pl->lds_nodes = ln;
   pl->lds_sph = ls;
@@ -186,7 +188,9 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   if (max_depth < 0) return fail(ctx, "negative max_depth");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   rtk::KParams p{};
-  p.nodes = ps->nodes; p.sph = ps->sph; p.col = ps->col;
+  p.nodes = ps->nodes; p.nodes64 = ps->nodes64; p.sph = ps->sph; p.col = ps->col;
+  std::copy(ps->root_lo, ps->root_lo + 3, p.root_lo);
+  std::copy(ps->root_hi, ps->root_hi + 3, p.root_hi);
   p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
   std::memcpy(&p.cam, cam12 ? static_cast<const void *>(cam12) : static_cast<const void *>(&ps->cam), sizeof(p.cam));
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
@@ -427,6 +431,9 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   rc |= upload(ctx, &ps->right, bvh.right.data(), ni * sizeof(int32_t));
   rc |= upload(ctx, &ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
   rc |= upload(ctx, &ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
+  rc |= upload(ctx, &ps->nodes64, tl.nodes64.data(), ni * 64);
+  std::copy(tl.root_lo, tl.root_lo + 3, ps->root_lo);
+  std::copy(tl.root_hi, tl.root_hi + 3, ps->root_hi);
   rc |= upload(ctx, &ps->sph, tl.sph.data(), n * 16);
   rc |= upload(ctx, &ps->col, tl.col.data(), n * 16);
   // the host staging vectors die at scope exit: drain the copies first
@@ -447,7 +454,8 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   }
   for (void *p : {static_cast<void *>(ps->L7), static_cast<void *>(ps->bmin), static_cast<void *>(ps->bmax),
                   static_cast<void *>(ps->left), static_cast<void *>(ps->right), static_cast<void *>(ps->parent),
-                  static_cast<void *>(ps->nodes), static_cast<void *>(ps->sph), static_cast<void *>(ps->col)})
+                  static_cast<void *>(ps->nodes), static_cast<void *>(ps->nodes64), static_cast<void *>(ps->sph),
+                  static_cast<void *>(ps->col)})
     if (p) (void)hipFree(p);
   for (auto &o : ps->orders) {
     (void)hipFree(o.cost);
@@ -551,7 +559,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * 8 * static_cast<size_t>(nw)));
   RT_HIP(ctx, hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), ctx->stream));
   rtk::KParams p{};
-  p.nodes = ps->nodes; p.sph = ps->sph; p.col = ps->col;
+  p.nodes = ps->nodes; p.nodes64 = ps->nodes64; p.sph = ps->sph; p.col = ps->col;
+  std::copy(ps->root_lo, ps->root_lo + 3, p.root_lo);
+  std::copy(ps->root_hi, ps->root_hi + 3, p.root_hi);
   p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
   std::memcpy(&p.cam, &ps->cam, sizeof(p.cam));
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <numeric>
 
@@ -291,13 +292,33 @@ TravLayout make_trav_layout(const Lbvh &b) {
     nd.left = ref(b.left[c]);
     nd.right = ref(b.right[c]);
   }
+  t.nodes64.assign(16 * ni, 0.0f);
+  for (size_t ti = 0; ti < ni; ++ti) {
+    const TravNode &nd = t.nodes[ti];
+    float *q = &t.nodes64[16 * ti];
+    const int32_t kid[2] = {nd.left, nd.right};
+    for (int k = 0; k < 2; ++k) {
+      if (kid[k] < 0) continue;   // leaf child: no box
+      const TravNode &ch = t.nodes[static_cast<size_t>(kid[k])];
+      for (int a = 0; a < 3; ++a) {
+        q[8 * k + a] = ch.lo[a];
+        q[8 * k + 4 + a] = ch.hi[a];
+      }
+    }
+    std::memcpy(&q[3], &nd.left, 4);
+    std::memcpy(&q[7], &nd.right, 4);
+  }
+  for (int a = 0; a < 3; ++a) {
+    t.root_lo[a] = t.nodes[0].lo[a];
+    t.root_hi[a] = t.nodes[0].hi[a];
+  }
   t.sph.resize(4 * static_cast<size_t>(n));
   t.col.resize(4 * static_cast<size_t>(n));
   for (int64_t i = 0; i < n; ++i) {
     const Sphere &s = b.L[i];
     float *p = &t.sph[4 * static_cast<size_t>(i)], *c = &t.col[4 * static_cast<size_t>(i)];
     p[0] = s.px; p[1] = s.py; p[2] = s.pz; p[3] = s.radius;
-    c[0] = s.cr; c[1] = s.cg; c[2] = s.cb; c[3] = 0.0f;
+    c[0] = s.cr; c[1] = s.cg; c[2] = s.cb; c[3] = 1.0f / s.radius;
   }
   return t;
 }

@@ -146,10 +146,11 @@ RT_HD int32_t pack_pixel(float r, float g, float b) {   // colour_to_pixel, ray.
 // :119-124): re-intersect the winning sphere with (0.0, best+1), scatter or terminate.
 // Returns true when the pixel continues with the scattered ray (r, light, depth updated);
 // false when the pixel is finished and *pixel holds its packed colour.
-//   sph = {pos.xyz, radius}, col = colour of sphere bestj (ignored when bestj < 0).
+//   sph = {pos.xyz, radius}, col = colour of sphere bestj, inv_rad = 1.0f / radius as an IEEE
+//   division (the host tabulates it; ignored, like sph/col, when bestj < 0).
 RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float spz, float srad,
-                      float scr, float scg, float scb, float &lr, float &lg, float &lb, int &depth,
-                      int max_depth, int32_t *pixel) {
+                      float scr, float scg, float scb, float inv_rad, float &lr, float &lg, float &lb,
+                      int &depth, int max_depth, int32_t *pixel) {
   bool have = false;
   float t = 0.0f;
   if (bestj >= 0) {
@@ -173,7 +174,6 @@ RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float
   if (have) {
     // hit record (ray.fut:40-46)
     const float hpx = r.ox + t * r.dx, hpy = r.oy + t * r.dy, hpz = r.oz + t * r.dz;
-    const float inv_rad = 1.0f / srad;
     const float nx = inv_rad * (hpx - spx), ny = inv_rad * (hpy - spy), nz = inv_rad * (hpz - spz);
     // scatter (ray.fut:119-124), reflect (ray.fut:116-117)
     const float ux = inv_norm * r.dx, uy = inv_norm * r.dy, uz = inv_norm * r.dz;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
       s = p.sph[bestj];
       c = p.col[bestj];
     }
-    if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) break;
+    if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) break;
   }
   p.out[(size_t)lrow * p.w + col] = pixel;
   if (STATS) {
@@ -108,6 +108,19 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
 // ballot of a bool: the v_cmp result IS the 64-bit lane mask (HIP's __ballot(int) would go
 // bool -> int -> compare again)
 __device__ __forceinline__ unsigned long long bal(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+// v_cndmask_b32 driven directly by a 64-bit lane mask held in SGPRs: bit set -> b, else a.
+// (Written as asm because hipcc materialises `mask -> bool -> select` through VGPR 0/1 values.)
+__device__ __forceinline__ int sel_mask(unsigned long long m, int a, int b) {
+  int out;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(m));
+  return out;
+}
+
+// 32-bit store to an LDS byte address
+__device__ __forceinline__ void lds_store(int lds_byte_addr, unsigned v) {
+  *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((unsigned)lds_byte_addr) = v;
+}
 
 __device__ __forceinline__ int lane_rank(unsigned long long m) {   // # set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
           c = p.col[bestj];
         }
         int32_t pixel;
-        if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
+        if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
           cur = 0;
           best = kTMax;
           bestj = -1;
@@ -308,18 +321,19 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int sph_base = 2 * p.lds_nodes;
-  // per-wave region: key[64] (u64) | cnt[64] | box stack[capb] | leaf list[capl]
-  const int per_wave_dw = 128 + 64 + p.capb + p.capl;
+  const int sph_base = 4 * p.lds_nodes;   // 64-byte node records = 4 x float4
+  // per-wave region: key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl]
+  const int per_wave_dw = 128 + 64 + 4 + p.capb + p.capl;
   unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
   unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
   int *const wcnt = reinterpret_cast<int *>(wbase + 128);
-  unsigned *const wbox = wbase + 192;
+  unsigned *const wdump = wbase + 192;    // where lanes with nothing to append write
+  unsigned *const wbox = wbase + 196;
   unsigned *const wleaf = wbox + p.capb;
-  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes, (unsigned)p.n_nodes * 32u);
+  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
 
-  for (int i = threadIdx.x; i < 2 * p.lds_nodes; i += THREADS) smem[i] = p.nodes[i];
+  for (int i = threadIdx.x; i < 4 * p.lds_nodes; i += THREADS) smem[i] = p.nodes64[i];
   for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) smem[sph_base + i] = p.sph[i];
   // Zero the work lists: lanes without an item read a stale entry and compute on it with
   // their results masked off, so every stale entry must decode to valid indices.
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             c = p.col[bestj];
           }
           int32_t pixel;
-          if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
             root = true;
           } else {
             p.out[pix] = pixel;
@@ -420,13 +434,15 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           pix = slot;
           root = true;
         }
+        // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
+        const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
         if (root) {
           wkey[lane] = kKeyInit;
-          wcnt[lane] = 1;
-          if (STATS) n_rays++;
+          wcnt[lane] = root_hit ? 1 : 0;    // 0: the fold is already complete (a miss), shaded next time
+          if (STATS) { n_rays++; n_box++; }
         }
-        const unsigned long long m_root = bal(root);
-        if (root) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
+        const unsigned long long m_root = bal(root_hit);
+        if (root_hit) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
         nbox += __popcll(m_root);
         // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
         // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
@@ -466,50 +482,61 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const float g = sphere_root(q, s.x, s.y, s.z, s.w);
       if (act & (g < kTMax))
         atomicMin(&wkey[sl4 >> 2], ((unsigned long long)__float_as_uint(g) << 32) | (unsigned)jj);
-      if (act) atomicAdd(&wcnt[sl4 >> 2], -1);
+      atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
-      // ---- BOX: up to 64 (slot, node) items ----
+      // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
       if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
       const int top = nbox - 1 - lane;
       const unsigned item = wbox[top < 0 ? 0 : top];
-      const bool act = top >= 0;
       nbox = nbox > 64 ? nbox - 64 : 0;
       const int sl4 = (int)(item & 0xfcu);
       const int ni = (int)(item >> 8);
       Ray q;
       q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
       q.ix = pull(sl4, r.ix); q.iy = pull(sl4, r.iy); q.iz = pull(sl4, r.iz);
-      float4 lo, hi;
+      float4 q0, q1, q2, q3;
       if (ALL_LDS) {
-        lo = smem[2 * ni];
-        hi = smem[2 * ni + 1];
+        q0 = smem[4 * ni]; q1 = smem[4 * ni + 1]; q2 = smem[4 * ni + 2]; q3 = smem[4 * ni + 3];
       } else {
         const int li = ni < p.lds_nodes ? ni : 0;
-        lo = smem[2 * li];
-        hi = smem[2 * li + 1];
+        q0 = smem[4 * li]; q1 = smem[4 * li + 1]; q2 = smem[4 * li + 2]; q3 = smem[4 * li + 3];
         if (ni >= p.lds_nodes) {
-          lo = buf_load16(rs_nodes, ni * 32);
-          hi = buf_load16(rs_nodes, ni * 32 + 16);
+          q0 = buf_load16(rs_nodes, ni * 64);
+          q1 = buf_load16(rs_nodes, ni * 64 + 16);
+          q2 = buf_load16(rs_nodes, ni * 64 + 32);
+          q3 = buf_load16(rs_nodes, ni * 64 + 48);
         }
       }
-      const int cl = f2i(lo.w), cr = f2i(hi.w);
-      const bool hit = act && box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
-      if (STATS) n_box += act ? 1 : 0;
-      const bool lneg = cl < 0, rneg = cr < 0;
-      const bool inl = hit && !lneg, inr = hit && !rneg;
-      const bool lfl = hit && lneg, lfr = hit && rneg;
-      const unsigned long long m_inl = bal(inl), m_inr = bal(inr);
-      const unsigned long long m_lfl = bal(lfl), m_lfr = bal(lfr);
-      // left children first, then right children (two independent prefix ranks)
+      const int cl = f2i(q0.w), cr = f2i(q1.w);
+      // lane masks straight from the compares; the rest is 64-bit scalar logic
+      const unsigned long long m_act = bal(top >= 0);
+      const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
+      const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+      const unsigned long long m_ln = bal(cl < 0), m_rn = bal(cr < 0);
+      // an inner child continues iff its box passes; a leaf child is tested because this node passed
+      const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
+      const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
+      if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
+      // append: left children first, then right children (two independent prefix ranks);
+      // lanes with nothing to append write to the dump slot instead of being masked off
       const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-      if (inl) wbox[nbox + lane_rank(m_inl)] = ((unsigned)cl << 8) | (unsigned)sl4;
-      if (inr) wbox[nbox + c_inl + lane_rank(m_inr)] = ((unsigned)cr << 8) | (unsigned)sl4;
+      const int dump = (int)(size_t)(wdump) ;   // LDS byte address (low 32 bits of the flat address)
+      const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+      const int a_inl = sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl));
+      const int a_inr = sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr)));
+      const int a_lfl = sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl));
+      const int a_lfr = sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
+      const unsigned vl = ((unsigned)cl << 8) | (unsigned)sl4, vr = ((unsigned)cr << 8) | (unsigned)sl4;
+      lds_store(a_inl, vl);
+      lds_store(a_inr, vr);
+      lds_store(a_lfl, vl);
+      lds_store(a_lfr, vr);
       nbox += c_inl + __popcll(m_inr);
-      if (lfl) wleaf[nleaf + lane_rank(m_lfl)] = ((unsigned)cl << 8) | (unsigned)sl4;
-      if (lfr) wleaf[nleaf + c_lfl + lane_rank(m_lfr)] = ((unsigned)cr << 8) | (unsigned)sl4;
       nleaf += c_lfl + __popcll(m_lfr);
-      // one item consumed, two created on a hit: outstanding += hit ? +1 : -1
-      if (act) atomicAdd(&wcnt[sl4 >> 2], hit ? 1 : -1);
+      // one item consumed, k appended: outstanding += k - 1; lanes without an item add 0
+      const unsigned long long m_l = (m_act & (m_ln | m_hl)) | ~m_act, m_r = m_act & (m_rn | m_hr);
+      const int d0 = sel_mask(m_l, -1, 0);
+      atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_r, d0, d0 + 1));
     }
   }
   if (STATS) {
@@ -655,7 +682,7 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
 }
 
 size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg) {
-  return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (192 + capb + capl) * sizeof(unsigned);
+  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (196 + capb + capl) * sizeof(unsigned);
 }
 
 template <int THREADS, bool ALL_LDS, bool STATS>

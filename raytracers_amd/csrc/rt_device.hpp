@@ -12,8 +12,10 @@ constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)
   const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
+  const float4 *nodes64; // [4*(n-1)]  pooled family: {L.lo,left} {L.hi,right} {R.lo,0} {R.hi,0} (children's boxes)
   const float4 *sph;     // [n] {pos.xyz, radius}
-  const float4 *col;     // [n] {colour.rgb, 0}
+  const float4 *col;     // [n] {colour.rgb, 1/radius}
+  float root_lo[3], root_hi[3];   // the root's own box
   int n_nodes, n_sph;    // n-1, n
   Cam cam;
   // image + partition

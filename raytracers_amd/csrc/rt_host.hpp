@@ -73,7 +73,13 @@ static_assert(sizeof(TravNode) == 32, "TravNode must be 2 x float4");
 struct TravLayout {
   std::vector<TravNode> nodes;       // [n-1] breadth-first
   std::vector<float> sph;            // [n][4] pos.xyz, radius
-  std::vector<float> col;            // [n][4] colour.rgb, 0
+  std::vector<float> col;            // [n][4] colour.rgb, 1/radius (hit normal's scale, ray.fut:44)
+  // 64-byte records for the pooled kernel: a work item is an inner node whose own box already
+  // passed, so the record carries what its CHILDREN need: {L.lo.xyz, left} {L.hi.xyz, right}
+  // {R.lo.xyz, 0} {R.hi.xyz, 0}, where L/R are the child's box when the child is an inner node
+  // (unused for a leaf child: the reference keeps no leaf boxes, bvh.fut:84).
+  std::vector<float> nodes64;        // [n-1][16] breadth-first
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};   // box of the root (tested when a ray starts)
   std::vector<int32_t> bfs_of_canon; // canonical inner index -> traversal index
   int height = 0;                    // edges on the longest root -> leaf path
 };

@@ -89,7 +89,7 @@ static void render_simple(const SceneData &S, std::vector<int32_t> &out, Counter
         }
         F4 s{0, 0, 0, 1}, c{0, 0, 0, 0};
         if (bestj >= 0) { s = S.sph[bestj]; c = S.col[bestj]; }
-        if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, lr, lg, lb, depth, S.max_depth, &pixel)) break;
+        if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, S.max_depth, &pixel)) break;
       }
       out[(size_t)row * S.w + col] = pixel;
       if (S.depth_hist) {
@@ -181,7 +181,7 @@ static bool wave_step(Wave &W, const SceneData &S, const Policy &P, unsigned &ne
         F4 s{0, 0, 0, 1}, c{0, 0, 0, 0};
         if (L.bestj >= 0) { s = S.sph[L.bestj]; c = S.col[L.bestj]; }
         int32_t pixel;
-        if (finish_ray(L.r, L.best, L.bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, L.lr, L.lg, L.lb, L.depth, S.max_depth,
+        if (finish_ray(L.r, L.best, L.bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, L.lr, L.lg, L.lb, L.depth, S.max_depth,
                        &pixel)) {
           L.cur = 0; L.best = kTMax; L.bestj = -1;
           C.rays++;
@@ -334,7 +334,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
         F4 sp{0, 0, 0, 1}, c{0, 0, 0, 0};
         if (bestj >= 0) { sp = S.sph[bestj]; c = S.col[bestj]; }
         int32_t pixel;
-        if (finish_ray(s.r, best, bestj, sp.x, sp.y, sp.z, sp.w, c.x, c.y, c.z, s.lr, s.lg, s.lb, s.depth, S.max_depth, &pixel)) {
+        if (finish_ray(s.r, best, bestj, sp.x, sp.y, sp.z, sp.w, c.x, c.y, c.z, c.w, s.lr, s.lg, s.lb, s.depth, S.max_depth, &pixel)) {
           s.key = kKeyInit; s.cnt = 1;
           W.box.push_back(((unsigned)l << 26) | 0u);
           C.rays++;
