@@ -138,7 +138,7 @@ struct Plan {
 // Decide the launch shape of the persistent family for one prepared scene.
 int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   pl->variant = ctx->variant;
-  if (pl->variant == RT_VARIANT_AUTO) pl->variant = ps->n < (int64_t(1) << 23) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
+  if (pl->variant == RT_VARIANT_AUTO) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
   if (pl->variant == RT_VARIANT_PIXEL) return 0;
   const int ni = static_cast<int>(ps->n - 1), n = static_cast<int>(ps->n);
   // depth-first with one node held in a register: at most one pending sibling per level
@@ -196,6 +196,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
   p.rows_local = static_cast<int>(rt::part_rows(h, rows_per_tile, part, nparts));
   p.rows_per_tile = rows_per_tile; p.part = part; p.nparts = nparts;
+  p.rpt_log2 = (rows_per_tile & (rows_per_tile - 1)) == 0 ? __builtin_ctz(rows_per_tile) : -1;
   p.tiles_x = (p.w + 7) / 8;
   p.max_depth = max_depth;
   p.out = out_dev;
@@ -222,7 +223,8 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.capb = pl.capb; p.capl = pl.capl;
   p.prio_depth = ctx->prio_depth;
   if (pl.variant == RT_VARIANT_POOLED) {
-    if (ps->n >= (int64_t(1) << 23)) return fail(ctx, "pooled kernel: at most 2^23 spheres (work items carry 24-bit references)");
+    if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
+    if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
     TileOrder *to = nullptr;
     if (ctx->adaptive_order) {
@@ -247,13 +249,16 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
         ps->orders.push_back(o);
         to = &ps->orders.back();
       }
-      p.cost = to->cost;
+      // The record of a view is a deterministic function of the view, so the table is computed
+      // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
+      // recomputes every frame (testing aid).
+      const bool rerecord = !to->valid || ctx->adaptive_order == 2;
+      p.cost = rerecord ? to->cost : nullptr;
       p.order = to->valid ? to->order : nullptr;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
-    if (to && (!to->valid || ctx->adaptive_order == 1)) {
-      // next frame's ticket -> tile table from this frame's record (also clears the record);
-      // adaptive_order == 2 computes the table once per view and then keeps it
+    if (to && p.cost) {
+      // next frames' ticket -> tile table from this frame's record (also clears the record)
       RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, ctx->stream));
       to->valid = true;
     }
@@ -565,7 +570,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
   std::memcpy(&p.cam, &ps->cam, sizeof(p.cam));
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
-  p.rows_local = p.h; p.rows_per_tile = 8; p.part = 0; p.nparts = 1;
+  p.rows_local = p.h; p.rows_per_tile = 8; p.part = 0; p.nparts = 1; p.rpt_log2 = 3;
   p.tiles_x = (p.w + 7) / 8;
   p.max_depth = max_depth;
   p.out = tmp;

@@ -59,14 +59,11 @@ RT_HD float pixel_v(int row, int height) { return (float)(height - row) / (float
 // get_ray for precomputed (u, v): the pooled kernel reads u and v from per-column / per-row
 // tables the host fills with pixel_u / pixel_v (two correctly rounded divisions per pixel
 // become two loads; the values are the same bits).
-RT_HD Ray primary_ray_uv(const Cam &c, float u, float v) {
-  Ray r;
+RT_HD void primary_dir_uv(const Cam &c, float u, float v, Ray &r) {   // origin + direction only
   r.ox = c.ox; r.oy = c.oy; r.oz = c.oz;
   r.dx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
   r.dy = ((c.ly + u * c.hy) + v * c.vy) - c.oy;
   r.dz = ((c.lz + u * c.hz) + v * c.vz) - c.oz;
-  ray_derive(r);
-  return r;
 }
 
 RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
@@ -142,34 +139,64 @@ RT_HD int32_t pack_pixel(float r, float g, float b) {   // colour_to_pixel, ray.
   return (ir << 16) | (ig << 8) | ib;
 }
 
-// One iteration of ray_colour's loop body AFTER the fold (ray.fut:126-148, :83-86,
-// :119-124): re-intersect the winning sphere with (0.0, best+1), scatter or terminate.
-// Returns true when the pixel continues with the scattered ray (r, light, depth updated);
-// false when the pixel is finished and *pixel holds its packed colour.
-//   sph = {pos.xyz, radius}, col = colour of sphere bestj, inv_rad = 1.0f / radius as an IEEE
-//   division (the host tabulates it; ignored, like sph/col, when bestj < 0).
-RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float spz, float srad,
-                      float scr, float scg, float scb, float inv_rad, float &lr, float &lg, float &lb,
-                      int &depth, int max_depth, int32_t *pixel) {
+// sphere_root plus what the later re-intersection needs to know: *near_root is set when the
+// fold took root2 (root1 <= 0.1) although root1 > 0 -- exactly the case in which
+// `sphere_hit s r 0.0 (t+1)` (ray.fut:83-85) returns root1 instead of the fold's t.
+RT_HD float sphere_root_flag(const Ray &r, float px, float py, float pz, float rad, bool *near_root) {
+  const float ocx = r.ox - px, ocy = r.oy - py, ocz = r.oz - pz;
+  const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
+  const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rad * rad;
+  const float disc = b * b - r.a * c;
+  *near_root = false;
+  if (disc <= 0.0f) return kNoHit;
+  const float sq = sqrtf(disc);
+  float t = (-b - sq) / r.a;
+  if (!(t > kEps)) {
+    *near_root = t > 0.0f;
+    t = (-b + sq) / r.a;
+    if (!(t > kEps)) return kNoHit;
+  }
+  return t;
+}
+
+// The literal re-intersection of the winning sphere, `sphere_hit s r 0.0 (best+1)`
+// (ray.fut:83-85, :32-51): may pick the OTHER root than the fold did, or none.
+RT_HD bool rehit_full(const Ray &r, float best, float spx, float spy, float spz, float srad, float *t_out) {
+  const float ocx = r.ox - spx, ocy = r.oy - spy, ocz = r.oz - spz;
+  const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
+  const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - srad * srad;
+  const float disc = b * b - r.a * c;
   bool have = false;
   float t = 0.0f;
-  if (bestj >= 0) {
-    // sphere_hit s r 0.0 (t_max+1): may pick the OTHER root than the fold did, or none.
-    const float ocx = r.ox - spx, ocy = r.oy - spy, ocz = r.oz - spz;
-    const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
-    const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - srad * srad;
-    const float disc = b * b - r.a * c;
-    if (!(disc <= 0.0f)) {
-      const float sq = sqrtf(disc);
-      const float lim = best + 1.0f;
-      t = (-b - sq) / r.a;
+  if (!(disc <= 0.0f)) {
+    const float sq = sqrtf(disc);
+    const float lim = best + 1.0f;
+    t = (-b - sq) / r.a;
+    have = (t < lim) && (t > 0.0f);
+    if (!have) {
+      t = (-b + sq) / r.a;
       have = (t < lim) && (t > 0.0f);
-      if (!have) {
-        t = (-b + sq) / r.a;
-        have = (t < lim) && (t > 0.0f);
-      }
     }
   }
+  *t_out = t;
+  return have;
+}
+
+// Shortcut for the same call when the fold's accepted root `best` is known not to be
+// displaced: with near_root clear, root1 (if it was the fold's root) or root2 passes
+// `0 < t < best + 1` iff best + 1 > best, and the re-intersection returns t = best.
+// Returns false when the caller must run rehit_full instead.
+RT_HD bool rehit_is_best(float best, bool near_root) { return !near_root && (best + 1.0f > best); }
+
+// The rest of one ray_colour iteration (ray.fut:126-148, :119-124): scatter or terminate.
+// `have`/`t`: result of the re-intersection.  Returns true when the pixel continues with the
+// scattered ray: r.o/r.d, light and depth are updated (and, if DERIVE, r's derived fields;
+// otherwise the caller runs ray_derive); false when the pixel is finished and *pixel holds
+// its packed colour.  sph = {pos.xyz}, col = colour, inv_rad = 1.0f / radius as an IEEE
+// division (tabulated by the host).
+template <bool DERIVE>
+RT_HD bool shade_ray(Ray &r, bool have, float t, float spx, float spy, float spz, float scr, float scg, float scb,
+                     float inv_rad, float &lr, float &lg, float &lb, int &depth, int max_depth, int32_t *pixel) {
   const float inv_norm = 1.0f / sqrtf(r.a);   // normalise r.dir = scale (1/norm d) d
   if (have) {
     // hit record (ray.fut:40-46)
@@ -182,7 +209,7 @@ RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float
     if (dot3(rx, ry, rz, nx, ny, nz) > 0.0f && depth + 1 < max_depth) {
       r.ox = hpx; r.oy = hpy; r.oz = hpz;
       r.dx = rx; r.dy = ry; r.dz = rz;
-      ray_derive(r);
+      if (DERIVE) ray_derive(r);
       lr = lr * scr; lg = lg * scg; lb = lb * scb;
       depth = depth + 1;
       return true;
@@ -198,6 +225,16 @@ RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float
   const float sr = w * 1.0f + tt * 0.5f, sg = w * 1.0f + tt * 0.7f, sb = w * 1.0f + tt * 1.0f;
   *pixel = pack_pixel(lr * sr, lg * sg, lb * sb);
   return false;
+}
+
+// One whole iteration of ray_colour's loop body AFTER the fold: re-intersect the winning
+// sphere with (0.0, best+1), then scatter or terminate.
+RT_HD bool finish_ray(Ray &r, float best, int bestj, float spx, float spy, float spz, float srad,
+                      float scr, float scg, float scb, float inv_rad, float &lr, float &lg, float &lb,
+                      int &depth, int max_depth, int32_t *pixel) {
+  float t = 0.0f;
+  const bool have = bestj >= 0 && rehit_full(r, best, spx, spy, spz, srad, &t);
+  return shade_ray<true>(r, have, t, spx, spy, spz, scr, scg, scb, inv_rad, lr, lg, lb, depth, max_depth, pixel);
 }
 
 }  // namespace rtk

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int nbox = 0, nleaf = 0;
   unsigned q_next = 0, q_end = 0;
   int q_tile = 0;          // tile the current ticket maps to
+  int q_col0 = 0, q_row0 = 0;   // its first pixel column / local row
   int ptile = 0;           // (per lane) tile of the pixel in this slot, for the cost record
   bool exhausted = false;
   // instrumented build only: per-wave timeline (rt_render_trace)
@@ -378,14 +379,20 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
           const unsigned long long key = wkey[lane];
           const float best = __uint_as_float((unsigned)(key >> 32));
-          const int bestj = key == kKeyInit ? -1 : (int)(unsigned)(key & 0xffffffffull);
+          const bool hit = key != kKeyInit;
+          const int bestj = (int)((unsigned)key >> 1);
           float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bestj >= 0) {
+          if (hit) {
             s = p.sph[bestj];
             c = p.col[bestj];
           }
+          // the (0.0, t+1) re-intersection returns t = best unless the fold's root was
+          // displaced (near_root) or best+1 rounds to best: only then redo it literally
+          bool have = hit;
+          float t = best;
+          if (hit && !rehit_is_best(best, ((unsigned)key & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
           int32_t pixel;
-          if (finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          if (shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
             root = true;
           } else {
             p.out[pix] = pixel;
@@ -410,18 +417,23 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             q_next = t * 64u;
             q_end = q_next + 64u;
             q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
+            const int ty = q_tile / p.tiles_x;                    // once per ticket, scalar
+            q_col0 = (q_tile - ty * p.tiles_x) * 8;
+            q_row0 = ty * 8;
           }
           const unsigned avail = q_end - q_next;
           const unsigned rank = (unsigned)lane_rank(m);
           const unsigned cnt = (unsigned)__popcll(m);
           if (want & (rank < avail)) {
             const int within = (int)((q_next + rank) & 63u);
-            const int tx = q_tile % p.tiles_x, ty = q_tile / p.tiles_x;
-            const int col = tx * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+            const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
             if (col < p.w && lrow < p.rows_local) {
               slot = lrow * p.w + col;
               ptile = q_tile;
-              r = primary_ray_uv(p.cam, p.u_tab[col], p.v_tab[global_row(p, lrow)]);
+              // cyclic row tiles with rows_per_tile = 1 << rpt_log2 (division-free global_row)
+              const int k = lrow >> p.rpt_log2;
+              const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+              primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
               want = false;
             }
           }
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           root = true;
         }
         // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
+        if (root) ray_derive(r);   // one place for both scattered and primary rays
         const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
         if (root) {
           wkey[lane] = kKeyInit;
@@ -479,9 +492,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         if (jj >= p.lds_sph) s = buf_load16(rs_sph, jj * 16);
       }
       if (STATS) n_sph += act ? 1 : 0;
-      const float g = sphere_root(q, s.x, s.y, s.z, s.w);
+      bool near_root;
+      const float g = sphere_root_flag(q, s.x, s.y, s.z, s.w, &near_root);
+      // key = (bits(t), leaf << 1 | near_root): min = smallest t, ties to the lowest leaf
       if (act & (g < kTMax))
-        atomicMin(&wkey[sl4 >> 2], ((unsigned long long)__float_as_uint(g) << 32) | (unsigned)jj);
+        atomicMin(&wkey[sl4 >> 2],
+                  ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
       atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----

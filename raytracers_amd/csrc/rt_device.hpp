@@ -22,6 +22,7 @@ struct KParams {
   int w, h;              // full image
   int rows_local;        // rows of this part (packed)
   int rows_per_tile, part, nparts;
+  int rpt_log2;          // log2(rows_per_tile) when it is a power of two, else -1
   int tiles_x;           // ceil(w / 8)
   int max_depth;
   int32_t *out;          // [rows_local * w]

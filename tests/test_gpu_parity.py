@@ -200,7 +200,7 @@ def test_repeated_launches_share_the_ticket_counter(R, ctx, variant):
         assert (R.render(100, 36, ps_b) == wb).all()
 
 
-@pytest.mark.parametrize("adaptive", [0, 1])
+@pytest.mark.parametrize("adaptive", [0, 1, 2])
 @pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 200, 200)])
 def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive):
     """The pooled family reorders tiles by the previous frame's bounce-chain record.  Frames
