@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condenses a rocprofv3 output directory (CSV format) into the small text summaries kept
+under profiles/: per-kernel call count / total / mean / min / max duration from the
+kernel-trace, and (when present) the per-kernel mean of every PMC counter.
+
+  tools/rocpd_summary.py <rocprof_out_dir> [more dirs ...] > profiles/<name>.txt
+"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def main():
+    for d in sys.argv[1:]:
+        print(f"== {d}")
+        kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        dur = collections.defaultdict(list)
+        for f in kt:
+            for r in csv.DictReader(open(f)):
+                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if dur:
+            tot = sum(sum(v) for v in dur.values())
+            print("kernel-trace: name | calls | total_ns | mean_ns | min_ns | max_ns | % of GPU time")
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+                print(f"  {k[:90]} | {len(v)} | {sum(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | {100.0 * sum(v) / tot:.2f}")
+        cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        acc = collections.defaultdict(list)
+        for f in cc:
+            for r in csv.DictReader(open(f)):
+                acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if acc:
+            print("pmc: kernel | counter | dispatches | mean value per dispatch")
+            for (k, c), v in sorted(acc.items()):
+                print(f"  {k[:70]} | {c} | {len(v)} | {sum(v) / len(v):.1f}")
+
+
+if __name__ == "__main__":
+    main()
