@@ -304,10 +304,26 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // 64 items per "generation" with strictly increasing depth labels => size <= 64*H + 128.
 // The leaf list is drained first whenever it holds >= 64 items => size <= 63 + 128.
 // ---------------------------------------------------------------------------------
+constexpr unsigned kNoItem = 0xffffffffu;
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
 __device__ __forceinline__ float pull(int lane_byte, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
+}
+
+// Lanes that hold no box item take one from the top of the wave's LDS stack (newest first).
+// nbox is wave-uniform.  Lanes that take nothing read the dump slot.
+__device__ __forceinline__ void fill_from_stack(unsigned &cur, int &nbox, unsigned *wbox, unsigned *wdump) {
+  if (nbox == 0) return;                                   // uniform
+  const unsigned long long m_need = bal(cur == kNoItem);
+  if (m_need == 0ull) return;                              // uniform
+  const int rank = lane_rank(m_need);
+  const unsigned long long m_take = m_need & bal(rank < nbox);
+  const int addr = sel_mask(m_take, (int)(size_t)wdump, (int)(size_t)(wbox + nbox - 1) - 4 * rank);
+  const unsigned got = *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((unsigned)addr);
+  cur = (unsigned)sel_mask(m_take, (int)cur, (int)got);
+  const int need = __popcll(m_need);
+  nbox = nbox > need ? nbox - need : 0;
 }
 
 // Work items are one dword: (reference << 8) | (slot * 4).  The low byte is the owning
@@ -347,6 +363,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int depth = 0;
   int pix = -1;            // -1: slot empty
   unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
+  // ---- the box item this LANE currently holds (any slot's), kNoItem when none.  A lane keeps
+  // one passing child as its next item (no LDS round trip for it); the LDS stack only carries
+  // the surplus (second children, new roots) and feeds lanes that ran dry (fill_from_stack).
+  unsigned cur = kNoItem;
   // ---- wave state (uniform) ----
   int nbox = 0, nleaf = 0;
   unsigned q_next = 0, q_end = 0;
@@ -365,12 +385,14 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
     nbox = __builtin_amdgcn_readfirstlane(nbox);
     nleaf = __builtin_amdgcn_readfirstlane(nleaf);
-    if (nbox < 64 && nleaf < 64) {
-      // not a full wave of work in either list: look at completed folds / vacant slots
+    // Invariant: after fill_from_stack either every lane holds an item or the stack is empty.
+    const unsigned long long m_cur = bal(cur != kNoItem);
+    if (m_cur != ~0ull && nleaf < 64) {
+      // not a full wave of work: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
       const int ns = __popcll(bal(done | vacant));
-      if (ns >= p.thr_shade || (nbox | nleaf) == 0) {
+      if (ns >= p.thr_shade || (m_cur == 0ull && nleaf == 0)) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
@@ -457,6 +479,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const unsigned long long m_root = bal(root_hit);
         if (root_hit) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
         nbox += __popcll(m_root);
+        fill_from_stack(cur, nbox, wbox, wdump);
         // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
         // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
         // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         continue;
       }
     }
-    if (nleaf >= 64 || nbox == 0) {
+    if (nleaf >= 64 || m_cur == 0ull) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;
@@ -500,11 +523,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
       atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
-      // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
-      if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
-      const int top = nbox - 1 - lane;
-      const unsigned item = wbox[top < 0 ? 0 : top];
-      nbox = nbox > 64 ? nbox - 64 : 0;
+      // ---- BOX: every lane that holds an item tests the boxes of BOTH children of its node ----
+      if (STATS) { tr_ops[0]++; tr_items[0] += __popcll(m_cur); }
+      const unsigned item = cur != kNoItem ? cur : 0u;   // idle lanes compute on (node 0, slot 0), masked below
       const int sl4 = (int)(item & 0xfcu);
       const int ni = (int)(item >> 8);
       Ray q;
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       }
       const int cl = f2i(q0.w), cr = f2i(q1.w);
       // lane masks straight from the compares; the rest is 64-bit scalar logic
-      const unsigned long long m_act = bal(top >= 0);
+      const unsigned long long m_act = m_cur;
       const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
       const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
       const unsigned long long m_ln = bal(cl < 0), m_rn = bal(cr < 0);
@@ -533,26 +554,25 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
       const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
       if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
-      // append: left children first, then right children (two independent prefix ranks);
-      // lanes with nothing to append write to the dump slot instead of being masked off
-      const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-      const int dump = (int)(size_t)(wdump) ;   // LDS byte address (low 32 bits of the flat address)
-      const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
-      const int a_inl = sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl));
-      const int a_inr = sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr)));
-      const int a_lfl = sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl));
-      const int a_lfr = sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
       const unsigned vl = ((unsigned)cl << 8) | (unsigned)sl4, vr = ((unsigned)cr << 8) | (unsigned)sl4;
-      lds_store(a_inl, vl);
-      lds_store(a_inr, vr);
-      lds_store(a_lfl, vl);
-      lds_store(a_lfr, vr);
-      nbox += c_inl + __popcll(m_inr);
+      // the lane keeps one passing inner child (left first); a second one goes to the stack
+      const unsigned long long m_both = m_inl & m_inr;
+      const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
+      const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+      lds_store(sel_mask(m_both, dump, b_box + 4 * lane_rank(m_both)), vr);
+      nbox += __popcll(m_both);
+      cur = (unsigned)sel_mask(m_inl, sel_mask(m_inr, (int)kNoItem, (int)vr), (int)vl);
+      // leaf children: left ones first, then right ones (two independent prefix ranks); lanes
+      // with nothing to append write to the dump slot instead of being masked off
+      const int c_lfl = __popcll(m_lfl);
+      lds_store(sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl)), vl);
+      lds_store(sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr))), vr);
       nleaf += c_lfl + __popcll(m_lfr);
       // one item consumed, k appended: outstanding += k - 1; lanes without an item add 0
       const unsigned long long m_l = (m_act & (m_ln | m_hl)) | ~m_act, m_r = m_act & (m_rn | m_hr);
       const int d0 = sel_mask(m_l, -1, 0);
       atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_r, d0, d0 + 1));
+      fill_from_stack(cur, nbox, wbox, wdump);
     }
   }
   if (STATS) {
