@@ -378,6 +378,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   int tr_maxdepth = 0;
   if (STATS) tr_t0 = clock64();
+  if (STATS && p.prio_depth == 1000) {   // experiment: does s_setprio change a wave's share of the SIMD?
+    if ((wave & 3) == 0) __builtin_amdgcn_s_setprio(3);
+  }
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -392,7 +395,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
       const int ns = __popcll(bal(done | vacant));
-      if (ns >= p.thr_shade || (m_cur == 0ull && nleaf == 0)) {
+      // Once the tile queue is exhausted the wave only drains: let every fold in flight complete
+      // (no more SHADE by count), then leave the pooled loop -- the remaining bounce chains are
+      // finished by the per-lane epilogue below, which walks a lone ray ~3x faster.
+      const bool idle_now = m_cur == 0ull && nleaf == 0;
+      if (exhausted && p.epilogue) {
+        if (idle_now) break;
+      } else if (ns >= p.thr_shade || idle_now) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
@@ -573,6 +582,102 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const int d0 = sel_mask(m_l, -1, 0);
       atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_r, d0, d0 + 1));
       fill_from_stack(cur, nbox, wbox, wdump);
+    }
+  }
+  // ---- per-lane epilogue (drain phase) ---------------------------------------------------
+  // Every fold in flight has completed (results in wkey); the live slots are the pixels whose
+  // bounce chains go on.  From here each lane follows its own ray depth-first with a private
+  // stack (its column of the wave's box-stack region), sphere tests inline: no work lists, no
+  // bpermute, no atomics -- about one LDS round trip + ~70 instructions per visited node
+  // instead of one ~120-instruction wave operation per tree LEVEL.
+  if (p.epilogue) {
+    bool live = pix >= 0;
+    unsigned long long ekey = wkey[lane];
+    unsigned *const estack = wbox + lane;           // entry e at estack[e * 64]; capb / 64 >= height + 3
+    if (STATS) tr_exh = tr_exh ? tr_exh : clock64();
+    while (bal(live) != 0ull) {
+      if (live) {
+        // shade the completed fold
+        if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
+        const float best = __uint_as_float((unsigned)(ekey >> 32));
+        const bool hit = ekey != kKeyInit;
+        const int bestj = (int)((unsigned)ekey >> 1);
+        float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hit) {
+          s = p.sph[bestj];
+          c = p.col[bestj];
+        }
+        bool have = hit;
+        float t = best;
+        if (hit && !rehit_is_best(best, ((unsigned)ekey & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
+        int32_t pixel;
+        if (!shade_ray<true>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          p.out[pix] = pixel;
+          if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
+          pix = -1;
+          live = false;
+        }
+      }
+      if (live) {
+        // the next fold of this lane's ray, depth-first
+        if (STATS) { n_rays++; n_box++; }
+        ekey = kKeyInit;
+        if (box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2])) {
+          int sp = 0, ni = 0;
+          for (;;) {
+            float4 q0, q1, q2, q3;
+            if (ALL_LDS) {
+              q0 = smem[4 * ni]; q1 = smem[4 * ni + 1]; q2 = smem[4 * ni + 2]; q3 = smem[4 * ni + 3];
+            } else {
+              const int li = ni < p.lds_nodes ? ni : 0;
+              q0 = smem[4 * li]; q1 = smem[4 * li + 1]; q2 = smem[4 * li + 2]; q3 = smem[4 * li + 3];
+              if (ni >= p.lds_nodes) {
+                q0 = buf_load16(rs_nodes, ni * 64);
+                q1 = buf_load16(rs_nodes, ni * 64 + 16);
+                q2 = buf_load16(rs_nodes, ni * 64 + 32);
+                q3 = buf_load16(rs_nodes, ni * 64 + 48);
+              }
+            }
+            const int kid[2] = {f2i(q0.w), f2i(q1.w)};
+            const bool hl = box_hit(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+            const bool hr = box_hit(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              if (kid[k] < 0) {
+                const int j = ~kid[k];
+                float4 s;
+                if (ALL_LDS) {
+                  s = smem[sph_base + j];
+                } else {
+                  s = smem[sph_base + (j < p.lds_sph ? j : 0)];
+                  if (j >= p.lds_sph) s = buf_load16(rs_sph, j * 16);
+                }
+                if (STATS) n_sph++;
+                bool near_root;
+                const float g = sphere_root_flag(r, s.x, s.y, s.z, s.w, &near_root);
+                if (g < kTMax) {
+                  const unsigned long long key =
+                      ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)j << 1) | (near_root ? 1u : 0u);
+                  ekey = key < ekey ? key : ekey;
+                }
+              }
+            }
+            if (STATS) n_box += (kid[0] >= 0 ? 1 : 0) + (kid[1] >= 0 ? 1 : 0);
+            const bool inl = kid[0] >= 0 && hl, inr = kid[1] >= 0 && hr;
+            if (inl && inr) {
+              estack[(sp++) * 64] = (unsigned)kid[1];
+              ni = kid[0];
+            } else if (inl) {
+              ni = kid[0];
+            } else if (inr) {
+              ni = kid[1];
+            } else {
+              if (sp == 0) break;
+              ni = (int)estack[(--sp) * 64];
+            }
+          }
+        }
+      }
     }
   }
   if (STATS) {
