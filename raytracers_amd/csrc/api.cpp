@@ -38,7 +38,6 @@ struct rt_context {
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
-  int epilogue = 1;         // pooled family: per-lane epilogue for the drain phase
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
@@ -223,7 +222,6 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
   p.prio_depth = ctx->prio_depth;
-  p.epilogue = ctx->epilogue;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -361,8 +359,6 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_scene_bytes = v;
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
-  } else if (k == "epilogue") {
-    ctx->epilogue = v != 0;
   } else if (k == "prio_depth") {
     ctx->prio_depth = std::max(0, v);
   } else if (k == "adaptive_order") {
@@ -587,7 +583,6 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
   p.prio_depth = ctx->prio_depth;
-  p.epilogue = ctx->epilogue;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {

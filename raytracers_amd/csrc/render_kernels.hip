@@ -304,26 +304,10 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // 64 items per "generation" with strictly increasing depth labels => size <= 64*H + 128.
 // The leaf list is drained first whenever it holds >= 64 items => size <= 63 + 128.
 // ---------------------------------------------------------------------------------
-constexpr unsigned kNoItem = 0xffffffffu;
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
 __device__ __forceinline__ float pull(int lane_byte, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
-}
-
-// Lanes that hold no box item take one from the top of the wave's LDS stack (newest first).
-// nbox is wave-uniform.  Lanes that take nothing read the dump slot.
-__device__ __forceinline__ void fill_from_stack(unsigned &cur, int &nbox, unsigned *wbox, unsigned *wdump) {
-  if (nbox == 0) return;                                   // uniform
-  const unsigned long long m_need = bal(cur == kNoItem);
-  if (m_need == 0ull) return;                              // uniform
-  const int rank = lane_rank(m_need);
-  const unsigned long long m_take = m_need & bal(rank < nbox);
-  const int addr = sel_mask(m_take, (int)(size_t)wdump, (int)(size_t)(wbox + nbox - 1) - 4 * rank);
-  const unsigned got = *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((unsigned)addr);
-  cur = (unsigned)sel_mask(m_take, (int)cur, (int)got);
-  const int need = __popcll(m_need);
-  nbox = nbox > need ? nbox - need : 0;
 }
 
 // Work items are one dword: (reference << 8) | (slot * 4).  The low byte is the owning
@@ -363,10 +347,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int depth = 0;
   int pix = -1;            // -1: slot empty
   unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
-  // ---- the box item this LANE currently holds (any slot's), kNoItem when none.  A lane keeps
-  // one passing child as its next item (no LDS round trip for it); the LDS stack only carries
-  // the surplus (second children, new roots) and feeds lanes that ran dry (fill_from_stack).
-  unsigned cur = kNoItem;
   // ---- wave state (uniform) ----
   int nbox = 0, nleaf = 0;
   unsigned q_next = 0, q_end = 0;
@@ -378,9 +358,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   int tr_maxdepth = 0;
   if (STATS) tr_t0 = clock64();
-  if (STATS && p.prio_depth == 1000) {   // experiment: does s_setprio change a wave's share of the SIMD?
-    if ((wave & 3) == 0) __builtin_amdgcn_s_setprio(3);
-  }
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -388,20 +365,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
     nbox = __builtin_amdgcn_readfirstlane(nbox);
     nleaf = __builtin_amdgcn_readfirstlane(nleaf);
-    // Invariant: after fill_from_stack either every lane holds an item or the stack is empty.
-    const unsigned long long m_cur = bal(cur != kNoItem);
-    if (m_cur != ~0ull && nleaf < 64) {
-      // not a full wave of work: look at completed folds / vacant slots
+    if (nbox < 64 && nleaf < 64) {
+      // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
       const int ns = __popcll(bal(done | vacant));
-      // Once the tile queue is exhausted the wave only drains: let every fold in flight complete
-      // (no more SHADE by count), then leave the pooled loop -- the remaining bounce chains are
-      // finished by the per-lane epilogue below, which walks a lone ray ~3x faster.
-      const bool idle_now = m_cur == 0ull && nleaf == 0;
-      if (exhausted && p.epilogue) {
-        if (idle_now) break;
-      } else if (ns >= p.thr_shade || idle_now) {
+      if (ns >= p.thr_shade || (nbox | nleaf) == 0) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
@@ -488,7 +457,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const unsigned long long m_root = bal(root_hit);
         if (root_hit) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
         nbox += __popcll(m_root);
-        fill_from_stack(cur, nbox, wbox, wdump);
         // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
         // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
         // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
@@ -502,7 +470,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         continue;
       }
     }
-    if (nleaf >= 64 || m_cur == 0ull) {
+    if (nleaf >= 64 || nbox == 0) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;
@@ -532,9 +500,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
       atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
-      // ---- BOX: every lane that holds an item tests the boxes of BOTH children of its node ----
-      if (STATS) { tr_ops[0]++; tr_items[0] += __popcll(m_cur); }
-      const unsigned item = cur != kNoItem ? cur : 0u;   // idle lanes compute on (node 0, slot 0), masked below
+      // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
+      if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
+      const int top = nbox - 1 - lane;
+      const unsigned item = wbox[top < 0 ? 0 : top];
+      nbox = nbox > 64 ? nbox - 64 : 0;
       const int sl4 = (int)(item & 0xfcu);
       const int ni = (int)(item >> 8);
       Ray q;
@@ -555,7 +525,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       }
       const int cl = f2i(q0.w), cr = f2i(q1.w);
       // lane masks straight from the compares; the rest is 64-bit scalar logic
-      const unsigned long long m_act = m_cur;
+      const unsigned long long m_act = bal(top >= 0);
       const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
       const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
       const unsigned long long m_ln = bal(cl < 0), m_rn = bal(cr < 0);
@@ -563,121 +533,26 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
       const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
       if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
-      const unsigned vl = ((unsigned)cl << 8) | (unsigned)sl4, vr = ((unsigned)cr << 8) | (unsigned)sl4;
-      // the lane keeps one passing inner child (left first); a second one goes to the stack
-      const unsigned long long m_both = m_inl & m_inr;
-      const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
+      // append: left children first, then right children (two independent prefix ranks);
+      // lanes with nothing to append write to the dump slot instead of being masked off
+      const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
+      const int dump = (int)(size_t)(wdump) ;   // LDS byte address (low 32 bits of the flat address)
       const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
-      lds_store(sel_mask(m_both, dump, b_box + 4 * lane_rank(m_both)), vr);
-      nbox += __popcll(m_both);
-      cur = (unsigned)sel_mask(m_inl, sel_mask(m_inr, (int)kNoItem, (int)vr), (int)vl);
-      // leaf children: left ones first, then right ones (two independent prefix ranks); lanes
-      // with nothing to append write to the dump slot instead of being masked off
-      const int c_lfl = __popcll(m_lfl);
-      lds_store(sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl)), vl);
-      lds_store(sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr))), vr);
+      const int a_inl = sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl));
+      const int a_inr = sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr)));
+      const int a_lfl = sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl));
+      const int a_lfr = sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
+      const unsigned vl = ((unsigned)cl << 8) | (unsigned)sl4, vr = ((unsigned)cr << 8) | (unsigned)sl4;
+      lds_store(a_inl, vl);
+      lds_store(a_inr, vr);
+      lds_store(a_lfl, vl);
+      lds_store(a_lfr, vr);
+      nbox += c_inl + __popcll(m_inr);
       nleaf += c_lfl + __popcll(m_lfr);
       // one item consumed, k appended: outstanding += k - 1; lanes without an item add 0
       const unsigned long long m_l = (m_act & (m_ln | m_hl)) | ~m_act, m_r = m_act & (m_rn | m_hr);
       const int d0 = sel_mask(m_l, -1, 0);
       atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_r, d0, d0 + 1));
-      fill_from_stack(cur, nbox, wbox, wdump);
-    }
-  }
-  // ---- per-lane epilogue (drain phase) ---------------------------------------------------
-  // Every fold in flight has completed (results in wkey); the live slots are the pixels whose
-  // bounce chains go on.  From here each lane follows its own ray depth-first with a private
-  // stack (its column of the wave's box-stack region), sphere tests inline: no work lists, no
-  // bpermute, no atomics -- about one LDS round trip + ~70 instructions per visited node
-  // instead of one ~120-instruction wave operation per tree LEVEL.
-  if (p.epilogue) {
-    bool live = pix >= 0;
-    unsigned long long ekey = wkey[lane];
-    unsigned *const estack = wbox + lane;           // entry e at estack[e * 64]; capb / 64 >= height + 3
-    if (STATS) tr_exh = tr_exh ? tr_exh : clock64();
-    while (bal(live) != 0ull) {
-      if (live) {
-        // shade the completed fold
-        if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
-        const float best = __uint_as_float((unsigned)(ekey >> 32));
-        const bool hit = ekey != kKeyInit;
-        const int bestj = (int)((unsigned)ekey >> 1);
-        float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hit) {
-          s = p.sph[bestj];
-          c = p.col[bestj];
-        }
-        bool have = hit;
-        float t = best;
-        if (hit && !rehit_is_best(best, ((unsigned)ekey & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
-        int32_t pixel;
-        if (!shade_ray<true>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
-          p.out[pix] = pixel;
-          if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
-          pix = -1;
-          live = false;
-        }
-      }
-      if (live) {
-        // the next fold of this lane's ray, depth-first
-        if (STATS) { n_rays++; n_box++; }
-        ekey = kKeyInit;
-        if (box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2])) {
-          int sp = 0, ni = 0;
-          for (;;) {
-            float4 q0, q1, q2, q3;
-            if (ALL_LDS) {
-              q0 = smem[4 * ni]; q1 = smem[4 * ni + 1]; q2 = smem[4 * ni + 2]; q3 = smem[4 * ni + 3];
-            } else {
-              const int li = ni < p.lds_nodes ? ni : 0;
-              q0 = smem[4 * li]; q1 = smem[4 * li + 1]; q2 = smem[4 * li + 2]; q3 = smem[4 * li + 3];
-              if (ni >= p.lds_nodes) {
-                q0 = buf_load16(rs_nodes, ni * 64);
-                q1 = buf_load16(rs_nodes, ni * 64 + 16);
-                q2 = buf_load16(rs_nodes, ni * 64 + 32);
-                q3 = buf_load16(rs_nodes, ni * 64 + 48);
-              }
-            }
-            const int kid[2] = {f2i(q0.w), f2i(q1.w)};
-            const bool hl = box_hit(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-            const bool hr = box_hit(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              if (kid[k] < 0) {
-                const int j = ~kid[k];
-                float4 s;
-                if (ALL_LDS) {
-                  s = smem[sph_base + j];
-                } else {
-                  s = smem[sph_base + (j < p.lds_sph ? j : 0)];
-                  if (j >= p.lds_sph) s = buf_load16(rs_sph, j * 16);
-                }
-                if (STATS) n_sph++;
-                bool near_root;
-                const float g = sphere_root_flag(r, s.x, s.y, s.z, s.w, &near_root);
-                if (g < kTMax) {
-                  const unsigned long long key =
-                      ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)j << 1) | (near_root ? 1u : 0u);
-                  ekey = key < ekey ? key : ekey;
-                }
-              }
-            }
-            if (STATS) n_box += (kid[0] >= 0 ? 1 : 0) + (kid[1] >= 0 ? 1 : 0);
-            const bool inl = kid[0] >= 0 && hl, inr = kid[1] >= 0 && hr;
-            if (inl && inr) {
-              estack[(sp++) * 64] = (unsigned)kid[1];
-              ni = kid[0];
-            } else if (inl) {
-              ni = kid[0];
-            } else if (inr) {
-              ni = kid[1];
-            } else {
-              if (sp == 0) break;
-              ni = (int)estack[(--sp) * 64];
-            }
-          }
-        }
-      }
     }
   }
   if (STATS) {

@@ -37,18 +37,9 @@ tot = ops.sum(axis=1)
 print(f"  ops/wave: mean {tot.mean():.0f} max {tot.max()}  (BOX {ops[:,0].sum()} LEAF {ops[:,1].sum()} SHADE {ops[:,2].sum()})")
 print(f"  lane efficiency: BOX {items_box.sum() / (64.0 * ops[:,0].sum()):.3f} LEAF {items_leaf.sum() / (64.0 * ops[:,1].sum()):.3f}")
 print(f"  clk per op (lifetime / ops): mean {(life / np.maximum(tot, 1)).mean():.0f}")
-busy = tot > 100
-if busy.any():
-    print(f"  waves with > 100 ops: {busy.sum()}, clk/op mean {(life[busy] / tot[busy]).mean():.0f} min {(life[busy] / tot[busy]).min():.0f}")
 late = np.argsort(end)[-8:]
 for i in late[::-1]:
     print(f"    wave {i:5d}: end {end[i]:9d} exhausted {exh[i]:9d} ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}"
           f" drain clk/op {(end[i]-exh[i]) / max(1, 1):.0f}")
-if "prio_depth=1000" in sys.argv:
-    cpo = life / np.maximum(tot, 1)
-    w = np.arange(n.value) % 8
-    for k in range(8):
-        sel = (w == k) & (tot > 100)
-        print(f"    wave%8=={k}: mean clk/op {cpo[sel].mean():.0f} (n={sel.sum()})")
 # drain phase: ops after exhaustion are unknown per wave, but the time is:
 print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.0f} max {np.max(end - exh)} clk")
