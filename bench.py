@@ -10,6 +10,13 @@ A "step" is one frame of EACH scene of the headline metric (BASELINE.json: "Mray
 frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total work fixed) and
 the framebuffer is gathered to rank 0 over RCCL inside the timed region.
 
+Steps are independent frames, so up to --frames-in-flight of them (default 4) are enqueued
+on separate HIP streams, each with its own context and framebuffers: a 1000x1000 frame ends
+with a long tail in which a handful of 50-bounce pixels keep a few waves busy (the frame's
+latency floor), and the next frames' bulk work fills the otherwise idle machine.  All K
+steps complete inside the barrier/synchronize bracket.  The line also reports the strictly
+serial figures (one frame at a time, `serial`), measured right after the timed region.
+
 value = rays of all K steps / wall time (max over ranks), in Mray/s; a ray = one objs_hit
 call (futhark/ray.fut:130).  Ray and box/sphere-test counts come from an instrumented launch
 and are cross-checked against the oracle-derived constants below.
@@ -90,6 +97,8 @@ def main():
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="independent steps enqueued concurrently (streams)")
+    ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,10 +122,19 @@ def main():
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
-    renderers = []
-    for scene, h, w in frames:
-        pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=opts)
-        renderers.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
+    S = max(1, args.frames_in_flight)
+    # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
+    streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
+    lanes = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            lane = []
+            for scene, h, w in frames:
+                pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=opts)
+                lane.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
+            lanes.append(lane)
+    torch.cuda.synchronize()
+    renderers = lanes[0]
 
     # work per frame: instrumented launch (rank 0 is enough), checked against the oracle table
     work = {}
@@ -128,9 +146,11 @@ def main():
             raise SystemExit(f"work counters of {scene} {w}x{h} differ from the oracle's: {got} vs {want}")
         work[(scene, h, w)] = got
 
-    def step(events=None):
-        for i, (_, _, _, _, sr) in enumerate(renderers):
-            sr.render(events[i] if events is not None else None)
+    def step(k, events=None, nlanes=S):
+        li = k % nlanes
+        with torch.cuda.stream(streams[li]):
+            for i, (_, _, _, _, sr) in enumerate(lanes[li]):
+                sr.render(events[i] if events is not None else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -138,24 +158,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in renderers]
-          for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(nsteps, nlanes):
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
+              for _ in range(nsteps)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            step(k, ev[k], nlanes)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # per-launch durations on this rank: events recorded on the stream each kernel is launched on
+        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nsteps)])) for i in range(len(frames))]
+        return dt, kms
 
-    # per-launch kernel durations on this rank (events on the launch stream = torch's current stream)
-    kern_ms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
-               for i in range(len(renderers))]
+    for k in range(max(args.warmup, S)):
+        step(k)
+    elapsed, kern_ms = timed(args.steps, S)
+    serial = None
+    if S > 1 and not args.no_serial_extra:
+        serial = timed(max(10, args.steps // 2), 1)
 
     if rank == 0:
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
@@ -179,17 +204,29 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
-                       "options": opts, "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
+                       "options": opts, "frames_in_flight": S,
+                       "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
                          + f" on {dscene} {dw}x{dh}",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
                          "note": "achieved = algorithmic bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) / mean "
-                                 "launch time; the scene is LDS/L2 resident so real HBM traffic is ~4 B/pixel"},
+                                 "launch time of the dominant kernel in the timed region (launches of up to "
+                                 "frames_in_flight frames overlap, which stretches each one); the scene is LDS/L2 "
+                                 "resident so real HBM traffic is a few MB per frame"},
             "per_scene": per_scene,
             "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
                                   "note": "README.md:50 render times / oracle ray counts; different hardware"},
         }
+        if serial is not None:
+            sdt, skms = serial
+            nser = max(10, args.steps // 2)
+            out["serial"] = {
+                "note": "one frame at a time on one stream (no frames overlapped), measured after the timed region",
+                "value": rays_step * nser / sdt / 1e6, "ms_per_step": sdt / nser * 1e3,
+                "kernel_ms": {f"{sc}_{w}x{h}": skms[i] for i, (sc, h, w) in enumerate(frames)},
+                "roofline_frac": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
+                                  / (skms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS for i, (sc, h, w) in enumerate(frames)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out), flush=True)
