@@ -16,6 +16,10 @@ $(OBJ)/render_kernels.o: $(CSRC)/render_kernels.hip $(CSRC)/lane_core.h $(CSRC)/
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(OBJ)/bvh_build.o: $(CSRC)/bvh_build.hip $(CSRC)/rt_device.hpp $(CSRC)/lane_core.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -24,7 +28,7 @@ $(OBJ)/host_build.o: $(CSRC)/host_build.cpp $(CSRC)/rt_host.hpp
 	@mkdir -p $(OBJ)
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
-$(LIB): $(OBJ)/render_kernels.o $(OBJ)/api.o $(OBJ)/host_build.o
+$(LIB): $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o $(OBJ)/api.o $(OBJ)/host_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # native harness (our own bench front-end; the reference's futhark/main.c links the same way)

@@ -40,6 +40,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The frames in flight live on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES
+# hardware queues (default 4, and torch / RCCL take some), and streams that share a queue
+# serialise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 # (rays, box tests, sphere tests) per frame, from the CPU oracle (tests/test_oracle_golden.py

@@ -533,13 +533,21 @@ int orc_render_rows(const orc_bvh *objs, const orc_camera *cam, int64_t width, i
 #else
   (void)threads;
 #endif
+  /* rows are cut into column chunks so that a many-core host (the GPU box has 256 hardware
+   * threads) still sees thousands of tasks; dynamic schedule because work per pixel varies a lot */
+  const int64_t chunk = width >= 256 ? 128 : width;
+  const int64_t nchunk = (width + chunk - 1) / chunk;
+  const int64_t ntask = (row_end - row_begin) * nchunk;
 #pragma omp parallel
   {
     orc_counters c;
     memset(&c, 0, sizeof c);
 #pragma omp for schedule(dynamic, 1)
-    for (int64_t j = row_begin; j < row_end; j++) {
-      for (int64_t i = 0; i < width; i++) {
+    for (int64_t task = 0; task < ntask; task++) {
+      const int64_t j = row_begin + task / nchunk;
+      const int64_t i0 = (task % nchunk) * chunk;
+      const int64_t i1 = i0 + chunk < width ? i0 + chunk : width;
+      for (int64_t i = i0; i < i1; i++) {
         float u = (float)i / (float)width;
         float v = (float)(height - j) / (float)height;     /* pixel j i -> trace_ray ... (height-j) i */
         ray r = get_ray(cam, u, v);

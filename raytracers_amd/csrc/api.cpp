@@ -37,6 +37,7 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
@@ -361,6 +362,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_sph_first = v != 0;
   } else if (k == "prio_depth") {
     ctx->prio_depth = std::max(0, v);
+  } else if (k == "gpu_build") {
+    ctx->gpu_build = v != 0;
   } else if (k == "adaptive_order") {
     ctx->adaptive_order = v;
   } else {
@@ -420,32 +423,57 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   if (h <= 0 || w <= 0) return fail(ctx, "image size must be positive");
   if (scene->desc.spheres.size() < 2) return fail(ctx, "scene needs at least 2 spheres");
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
-  const rt::TravLayout tl = rt::make_trav_layout(bvh);
   auto ps = std::make_unique<rt_prepared>();
-  ps->n = bvh.n;
+  const size_t n = scene->desc.spheres.size(), ni = n - 1;
+  ps->n = static_cast<int64_t>(n);
   ps->h = h; ps->w = w;
   ps->cam = rt::scene_camera(scene->desc, h, w);
-  ps->height = tl.height;
-  const size_t n = static_cast<size_t>(bvh.n), ni = n - 1;
   int rc = 0;
-  rc |= upload(ctx, &ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
-  rc |= upload(ctx, &ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
-  rc |= upload(ctx, &ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
-  rc |= upload(ctx, &ps->left, bvh.left.data(), ni * sizeof(int32_t));
-  rc |= upload(ctx, &ps->right, bvh.right.data(), ni * sizeof(int32_t));
-  rc |= upload(ctx, &ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
-  rc |= upload(ctx, &ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
-  rc |= upload(ctx, &ps->nodes64, tl.nodes64.data(), ni * 64);
-  std::copy(tl.root_lo, tl.root_lo + 3, ps->root_lo);
-  std::copy(tl.root_hi, tl.root_hi + 3, ps->root_hi);
-  rc |= upload(ctx, &ps->sph, tl.sph.data(), n * 16);
-  rc |= upload(ctx, &ps->col, tl.col.data(), n * 16);
-  // the host staging vectors die at scope exit: drain the copies first
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipSuccess;
+  if (ctx->gpu_build && n < (size_t(1) << 27)) {
+    // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
+    float *sph7 = nullptr;
+    rc |= upload(ctx, &sph7, scene->desc.spheres.data(), n * sizeof(rt::Sphere));
+    auto dmalloc = [&](auto **p, size_t bytes) {
+      if (!rc && hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(bytes, 16)) != hipSuccess) rc = fail(ctx, "hipMalloc failed");
+    };
+    dmalloc(&ps->L7, n * 28); dmalloc(&ps->bmin, ni * 12); dmalloc(&ps->bmax, ni * 12);
+    dmalloc(&ps->left, ni * 4); dmalloc(&ps->right, ni * 4); dmalloc(&ps->parent, ni * 4);
+    dmalloc(&ps->nodes, ni * 32); dmalloc(&ps->nodes64, ni * 64); dmalloc(&ps->sph, n * 16); dmalloc(&ps->col, n * 16);
+    if (!rc) {
+      rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
+      e = rtk::gpu_build_bvh(sph7, static_cast<int>(n), o, ctx->stream, &ps->height);
+      float root[8];
+      if (e == hipSuccess) e = hipMemcpyAsync(root, ps->nodes, sizeof root, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) {
+        std::copy(root, root + 3, ps->root_lo);
+        std::copy(root + 4, root + 7, ps->root_hi);
+      }
+    }
+    if (sph7) (void)hipFree(sph7);
+  } else {
+    const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
+    const rt::TravLayout tl = rt::make_trav_layout(bvh);
+    ps->height = tl.height;
+    rc |= upload(ctx, &ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
+    rc |= upload(ctx, &ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
+    rc |= upload(ctx, &ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
+    rc |= upload(ctx, &ps->left, bvh.left.data(), ni * sizeof(int32_t));
+    rc |= upload(ctx, &ps->right, bvh.right.data(), ni * sizeof(int32_t));
+    rc |= upload(ctx, &ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
+    rc |= upload(ctx, &ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
+    rc |= upload(ctx, &ps->nodes64, tl.nodes64.data(), ni * 64);
+    std::copy(tl.root_lo, tl.root_lo + 3, ps->root_lo);
+    std::copy(tl.root_hi, tl.root_hi + 3, ps->root_hi);
+    rc |= upload(ctx, &ps->sph, tl.sph.data(), n * 16);
+    rc |= upload(ctx, &ps->col, tl.col.data(), n * 16);
+    // the host staging vectors die at scope exit: drain the copies first
+    e = hipStreamSynchronize(ctx->stream);
+  }
   if (rc || e != hipSuccess) {
     rt_prepared_free(ctx, ps.release());
-    return rc ? rc : hip_fail(ctx, e, "hipStreamSynchronize");
+    return rc ? rc : hip_fail(ctx, e, "rt_prepare_scene");
   }
   *out = ps.release();
   return 0;

@@ -51,6 +51,17 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg);
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
 size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg);
+// prepare_scene on the GPU (bvh_build.hip).  Canonical {L, I} arrays + the traversal copy.
+struct GpuBvhOut {
+  float *L7;                 // [n][7]
+  float *bmin, *bmax;        // [n-1][3]
+  int *left, *right, *parent;   // [n-1]  ptr: inner i -> i, leaf i -> -2 - i
+  float4 *nodes32;           // [2*(n-1)]
+  float4 *nodes64;           // [4*(n-1)]
+  float4 *sph, *col;         // [n]
+};
+hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, hipStream_t stream, int *height_out);
+
 hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);

@@ -45,9 +45,14 @@ def _scene(ctx, scene):
 
 
 # ---------------------------------------------------------------- BVH + camera ------------
-@pytest.mark.parametrize("scene", ["rgbbox", "irreg", "floor:37:222", "floor:2:12"])
-def test_bvh_arrays_bit_exact(R, ctx, scene):
+@pytest.mark.parametrize("gpu_build", [1, 0])
+@pytest.mark.parametrize("scene", ["rgbbox", "irreg", "floor:37:222", "floor:2:12", "floor:300:1800"])
+def test_bvh_arrays_bit_exact(R, ctx, scene, gpu_build):
+    """prepare_scene's {L, I} (bvh.fut:28) from the GPU builder (bvh_build.hip) and from the
+    host builder, both against the oracle: spheres, child pointers, parents and boxes bit-exact."""
+    ctx.set_option("gpu_build", gpu_build)
     ps = R.prepare_scene(40, 56, _scene(ctx, scene))
+    ctx.set_option("gpu_build", 1)
     got = ps.bvh_arrays()
     want = _oracle(scene).arrays()
     for k in ("left", "right", "parent"):
@@ -125,6 +130,21 @@ def test_big_scene_million_spheres(R, ctx):
     for v in (1, 2, 3):
         ctx.set_variant(v)
         assert int((R.render(512, 512, ps) != ref).sum()) == 0, v
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_host_built_scene_renders_identically(R, variant):
+    """The two builders number the traversal copy differently (breadth-first vs by depth); pixels
+    must not care."""
+    c = R.Context()
+    c.set_variant(variant)
+    for scene in ("rgbbox", "irreg"):
+        want, _ = _oracle(scene).render(150, 170)
+        for gpu_build in (0, 1):
+            c.set_option("gpu_build", gpu_build)
+            got = R.render(150, 170, R.prepare_scene(150, 170, c.scene(scene)))
+            assert int((got != want).sum()) == 0, (scene, gpu_build)
+    c.close()
 
 
 def test_random_scene_with_duplicates_and_explicit_camera(R, ctx):
