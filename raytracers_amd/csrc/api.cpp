@@ -80,6 +80,7 @@ struct rt_prepared {
   int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
   // traversal copy
   float4 *nodes = nullptr, *nodes64 = nullptr, *sph = nullptr, *col = nullptr;
+  char *block = nullptr;   // one device allocation behind all of the arrays above
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
 };
 
@@ -430,16 +431,28 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   ps->cam = rt::scene_camera(scene->desc, h, w);
   int rc = 0;
   hipError_t e = hipSuccess;
+  // one device allocation for every array of the prepared scene (256-byte aligned pieces)
+  {
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
+    const size_t o_L7 = carve(n * 28), o_bmin = carve(ni * 12), o_bmax = carve(ni * 12), o_left = carve(ni * 4),
+                 o_right = carve(ni * 4), o_parent = carve(ni * 4), o_nodes = carve(ni * 32), o_nodes64 = carve(ni * 64),
+                 o_sph = carve(n * 16), o_col = carve(n * 16);
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ps->block), off));
+    char *b = ps->block;
+    ps->L7 = reinterpret_cast<float *>(b + o_L7); ps->bmin = reinterpret_cast<float *>(b + o_bmin);
+    ps->bmax = reinterpret_cast<float *>(b + o_bmax); ps->left = reinterpret_cast<int32_t *>(b + o_left);
+    ps->right = reinterpret_cast<int32_t *>(b + o_right); ps->parent = reinterpret_cast<int32_t *>(b + o_parent);
+    ps->nodes = reinterpret_cast<float4 *>(b + o_nodes); ps->nodes64 = reinterpret_cast<float4 *>(b + o_nodes64);
+    ps->sph = reinterpret_cast<float4 *>(b + o_sph); ps->col = reinterpret_cast<float4 *>(b + o_col);
+  }
+  auto put = [&](void *dst, const void *src, size_t bytes) {
+    if (!rc && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, "hipMemcpyAsync failed");
+  };
   if (ctx->gpu_build && n < (size_t(1) << 27)) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
     float *sph7 = nullptr;
     rc |= upload(ctx, &sph7, scene->desc.spheres.data(), n * sizeof(rt::Sphere));
-    auto dmalloc = [&](auto **p, size_t bytes) {
-      if (!rc && hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(bytes, 16)) != hipSuccess) rc = fail(ctx, "hipMalloc failed");
-    };
-    dmalloc(&ps->L7, n * 28); dmalloc(&ps->bmin, ni * 12); dmalloc(&ps->bmax, ni * 12);
-    dmalloc(&ps->left, ni * 4); dmalloc(&ps->right, ni * 4); dmalloc(&ps->parent, ni * 4);
-    dmalloc(&ps->nodes, ni * 32); dmalloc(&ps->nodes64, ni * 64); dmalloc(&ps->sph, n * 16); dmalloc(&ps->col, n * 16);
     if (!rc) {
       rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
       e = rtk::gpu_build_bvh(sph7, static_cast<int>(n), o, ctx->stream, &ps->height);
@@ -456,18 +469,18 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
     const rt::TravLayout tl = rt::make_trav_layout(bvh);
     ps->height = tl.height;
-    rc |= upload(ctx, &ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
-    rc |= upload(ctx, &ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
-    rc |= upload(ctx, &ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
-    rc |= upload(ctx, &ps->left, bvh.left.data(), ni * sizeof(int32_t));
-    rc |= upload(ctx, &ps->right, bvh.right.data(), ni * sizeof(int32_t));
-    rc |= upload(ctx, &ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
-    rc |= upload(ctx, &ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
-    rc |= upload(ctx, &ps->nodes64, tl.nodes64.data(), ni * 64);
+    put(ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
+    put(ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
+    put(ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
+    put(ps->left, bvh.left.data(), ni * sizeof(int32_t));
+    put(ps->right, bvh.right.data(), ni * sizeof(int32_t));
+    put(ps->parent, bvh.parent.data(), ni * sizeof(int32_t));
+    put(ps->nodes, tl.nodes.data(), ni * sizeof(rt::TravNode));
+    put(ps->nodes64, tl.nodes64.data(), ni * 64);
     std::copy(tl.root_lo, tl.root_lo + 3, ps->root_lo);
     std::copy(tl.root_hi, tl.root_hi + 3, ps->root_hi);
-    rc |= upload(ctx, &ps->sph, tl.sph.data(), n * 16);
-    rc |= upload(ctx, &ps->col, tl.col.data(), n * 16);
+    put(ps->sph, tl.sph.data(), n * 16);
+    put(ps->col, tl.col.data(), n * 16);
     // the host staging vectors die at scope exit: drain the copies first
     e = hipStreamSynchronize(ctx->stream);
   }
@@ -485,11 +498,7 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  for (void *p : {static_cast<void *>(ps->L7), static_cast<void *>(ps->bmin), static_cast<void *>(ps->bmax),
-                  static_cast<void *>(ps->left), static_cast<void *>(ps->right), static_cast<void *>(ps->parent),
-                  static_cast<void *>(ps->nodes), static_cast<void *>(ps->nodes64), static_cast<void *>(ps->sph),
-                  static_cast<void *>(ps->col)})
-    if (p) (void)hipFree(p);
+  if (ps->block) (void)hipFree(ps->block);
   for (auto &o : ps->orders) {
     (void)hipFree(o.cost);
     (void)hipFree(o.order);
@@ -687,6 +696,9 @@ struct futhark_context_config {
 };
 struct futhark_context {
   rt_context *rt = nullptr;
+  // freed images are kept for reuse: main.c frees and re-renders every run, and a
+  // hipFree/hipMalloc pair per frame costs more than the frame itself
+  std::vector<std::pair<int64_t, int32_t *>> image_pool;
   std::string pending;   // error not yet collected by futhark_context_get_error
   int logging = 0;
   uint64_t renders = 0, prepares = 0;
@@ -732,6 +744,7 @@ extern "C" struct futhark_context *futhark_context_new(struct futhark_context_co
 }
 extern "C" void futhark_context_free(struct futhark_context *ctx) {
   if (!ctx) return;
+  for (auto &e : ctx->image_pool) rt_device_free(ctx->rt, e.second);
   rt_context_destroy(ctx->rt);
   delete ctx;
 }
@@ -787,7 +800,14 @@ extern "C" int futhark_entry_render(struct futhark_context *ctx, struct futhark_
   if (!ctx || !ctx->rt || !out0 || !in2) return 1;
   auto img = std::make_unique<futhark_i32_2d>();
   void *dev = nullptr;
-  if (int rc = rt_device_alloc(ctx->rt, &dev, static_cast<int64_t>(sizeof(int32_t)) * in0 * in1)) return fut_fail(ctx, rc);
+  for (size_t i = 0; i < ctx->image_pool.size(); ++i)
+    if (ctx->image_pool[i].first == in0 * in1) {
+      dev = ctx->image_pool[i].second;   // same stream => the new frame orders after any pending use
+      ctx->image_pool.erase(ctx->image_pool.begin() + static_cast<long>(i));
+      break;
+    }
+  if (!dev)
+    if (int rc = rt_device_alloc(ctx->rt, &dev, static_cast<int64_t>(sizeof(int32_t)) * in0 * in1)) return fut_fail(ctx, rc);
   img->dev = static_cast<int32_t *>(dev);
   img->shape[0] = in0;
   img->shape[1] = in1;
@@ -806,7 +826,10 @@ extern "C" int futhark_values_i32_2d(struct futhark_context *ctx, struct futhark
 extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i32_2d *arr) {
   if (!arr) return 0;
   int rc = 0;
-  if (ctx && ctx->rt && arr->dev) rc = rt_device_free(ctx->rt, arr->dev);
+  if (ctx && ctx->rt && arr->dev) {
+    if (ctx->image_pool.size() < 4) ctx->image_pool.emplace_back(arr->shape[0] * arr->shape[1], arr->dev);
+    else rc = rt_device_free(ctx->rt, arr->dev);
+  }
   delete arr;
   return fut_fail(ctx, rc);
 }

@@ -394,23 +394,23 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, hipSt
   const int ni = n - 1;
   const int nb_n = cdiv(n, kBT), nb_ni = cdiv(ni, kBT);
   const int sort_blocks = cdiv(n, kBT * kSortE);
-  float *centres = nullptr, *partial = nullptr, *bounds = nullptr, *bufmin = nullptr, *bufmax = nullptr;
-  unsigned *keys[2] = {nullptr, nullptr}, *counts = nullptr;
-  int *vals[2] = {nullptr, nullptr}, *depth = nullptr, *trav_of = nullptr, *flags = nullptr;
   const int red_blocks = nb_n < 1024 ? nb_n : 1024;
-  BVH_HIP(hipMalloc((void **)&centres, sizeof(float) * 3 * (size_t)n));
-  BVH_HIP(hipMalloc((void **)&partial, sizeof(float) * 6 * (size_t)red_blocks));
-  BVH_HIP(hipMalloc((void **)&bounds, sizeof(float) * 8));
-  BVH_HIP(hipMalloc((void **)&keys[0], sizeof(unsigned) * (size_t)n));
-  BVH_HIP(hipMalloc((void **)&keys[1], sizeof(unsigned) * (size_t)n));
-  BVH_HIP(hipMalloc((void **)&vals[0], sizeof(int) * (size_t)n));
-  BVH_HIP(hipMalloc((void **)&vals[1], sizeof(int) * (size_t)n));
-  BVH_HIP(hipMalloc((void **)&counts, sizeof(unsigned) * 4 * (size_t)sort_blocks + 16));
-  BVH_HIP(hipMalloc((void **)&bufmin, sizeof(float) * 3 * (size_t)ni));
-  BVH_HIP(hipMalloc((void **)&bufmax, sizeof(float) * 3 * (size_t)ni));
-  BVH_HIP(hipMalloc((void **)&depth, sizeof(int) * (size_t)ni));
-  BVH_HIP(hipMalloc((void **)&trav_of, sizeof(int) * (size_t)ni));
-  BVH_HIP(hipMalloc((void **)&flags, sizeof(int) * 4));
+  // one scratch allocation, carved up (256-byte aligned pieces)
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
+  const size_t o_centres = carve(sizeof(float) * 3 * (size_t)n), o_partial = carve(sizeof(float) * 6 * (size_t)red_blocks),
+               o_bounds = carve(sizeof(float) * 8), o_k0 = carve(sizeof(unsigned) * (size_t)n),
+               o_k1 = carve(sizeof(unsigned) * (size_t)n), o_v0 = carve(sizeof(int) * (size_t)n),
+               o_v1 = carve(sizeof(int) * (size_t)n), o_counts = carve(sizeof(unsigned) * 4 * (size_t)sort_blocks + 16),
+               o_bufmin = carve(sizeof(float) * 3 * (size_t)ni), o_bufmax = carve(sizeof(float) * 3 * (size_t)ni),
+               o_depth = carve(sizeof(int) * (size_t)ni), o_trav = carve(sizeof(int) * (size_t)ni), o_flags = carve(sizeof(int) * 4);
+  char *scratch = nullptr;
+  BVH_HIP(hipMalloc((void **)&scratch, off));
+  float *centres = (float *)(scratch + o_centres), *partial = (float *)(scratch + o_partial), *bounds = (float *)(scratch + o_bounds);
+  unsigned *keys[2] = {(unsigned *)(scratch + o_k0), (unsigned *)(scratch + o_k1)}, *counts = (unsigned *)(scratch + o_counts);
+  int *vals[2] = {(int *)(scratch + o_v0), (int *)(scratch + o_v1)};
+  float *bufmin = (float *)(scratch + o_bufmin), *bufmax = (float *)(scratch + o_bufmax);
+  int *depth = (int *)(scratch + o_depth), *trav_of = (int *)(scratch + o_trav), *flags = (int *)(scratch + o_flags);
 
   // 1. centres, bounds, Morton keys
   hipLaunchKernelGGL(centres_minmax_kernel, dim3(red_blocks), dim3(kBT), 0, st, sph7_dev, n, centres, partial);
@@ -469,10 +469,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, hipSt
   BVH_HIP(hipMemcpyAsync(&maxdepth, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
   BVH_HIP(hipStreamSynchronize(st));
   *height_out = maxdepth + 1;   // levels of inner nodes == edges on the longest root -> leaf path
-  for (void *p : {(void *)centres, (void *)partial, (void *)bounds, (void *)keys[0], (void *)keys[1], (void *)vals[0],
-                  (void *)vals[1], (void *)counts, (void *)bufmin, (void *)bufmax, (void *)depth, (void *)trav_of,
-                  (void *)flags})
-    (void)hipFree(p);
+  (void)hipFree(scratch);
   return hipSuccess;
 }
 
