@@ -197,7 +197,8 @@ def main():
             per_scene[f"{scene}_{w}x{h}"] = {
                 "rays": r, "kernel_ms": kern_ms[i], "Mray_s_kernel": r / world / (kern_ms[i] * 1e-3) / 1e6,
                 "alg_bytes_per_launch": ba, "alg_GBs": ba / (kern_ms[i] * 1e-3) / 1e9}
-        dom = max(range(len(renderers)), key=lambda i: kern_ms[i])
+        # the dominant launch = the one that carries the most algorithmic work of the step
+        dom = max(range(len(renderers)), key=lambda i: per_scene[f"{frames[i][0]}_{frames[i][2]}x{frames[i][1]}"]["alg_bytes_per_launch"])
         dscene, dh, dw = frames[dom]
         dkey = f"{dscene}_{dw}x{dh}"
         achieved = per_scene[dkey]["alg_GBs"]
@@ -225,6 +226,8 @@ def main():
         }
         if serial is not None:
             sdt, skms = serial
+            out["roofline"]["frac_one_frame_at_a_time"] = (bytes_alg(work[frames[dom]][1], work[frames[dom]][2], dh, dw) / world
+                                                          / (skms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS)
             nser = max(10, args.steps // 2)
             out["serial"] = {
                 "note": "one frame at a time on one stream (no frames overlapped), measured after the timed region",
