@@ -97,6 +97,11 @@ int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t npa
 int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t part, int32_t nparts,
                   const int32_t *part_dev, int32_t *image_dev);
 
+/* The same for ALL parts at once: stacked_dev = nparts x pad_rows x w int32 (what a gather of the
+ * ranks' padded send buffers delivers on rank 0), one kernel. */
+int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t pad_rows,
+                   const int32_t *stacked_dev, int32_t *image_dev);
+
 /* Work counters of one frame, computed on the device by an instrumented launch of the
  * same traversal: rays (objs_hit calls), box tests, sphere tests. */
 int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,

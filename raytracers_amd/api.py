@@ -255,3 +255,9 @@ def render_timed(out_ptr, h, w, prepared, warmup, iters, max_depth=MAX_DEPTH, pa
 def place_part(ctx, h, w, part, nparts, part_ptr, image_ptr, rows_per_tile=ROWS_PER_TILE):
     ctx._check(lib.rt_place_part(ctx._h, int(h), int(w), int(rows_per_tile), int(part), int(nparts),
                                  C.c_void_p(part_ptr), C.c_void_p(image_ptr)))
+
+
+def place_parts(ctx, h, w, nparts, pad_rows, stacked_ptr, image_ptr, rows_per_tile=ROWS_PER_TILE):
+    """All gathered parts (nparts x pad_rows x w) -> the h x w image, one kernel."""
+    ctx._check(lib.rt_place_parts(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(pad_rows),
+                                  C.c_void_p(stacked_ptr), C.c_void_p(image_ptr)))

@@ -66,4 +66,7 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stre
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 
+hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
+                            int pad_rows, hipStream_t stream);
+
 }  // namespace rtk

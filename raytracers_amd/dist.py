@@ -55,6 +55,9 @@ class HipPartRenderer:
     def place(self, part, nparts, part_tensor, image):
         api.place_part(self.ctx, self.h, self.w, part, nparts, part_tensor.data_ptr(), image.data_ptr())
 
+    def place_all(self, nparts, pad_rows, stacked, image):
+        api.place_parts(self.ctx, self.h, self.w, nparts, pad_rows, stacked.data_ptr(), image.data_ptr())
+
 
 class ShardedRenderer:
     """render(h, w) across the ranks of a torch.distributed group: each rank renders its
@@ -70,12 +73,20 @@ class ShardedRenderer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pad_rows = max_part_rows(h, self.world)
-        self.send = torch.zeros((self.pad_rows, w), dtype=torch.int32, device=self.device)
+        self.recv_all = None
         self.recv = None
         self.image = None
         if self.rank == dst:
-            self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
             self.image = torch.empty((h, w), dtype=torch.int32, device=self.device)
+        if self.world == 1:
+            self.send = self.image            # one part == the whole image: nothing to gather or assemble
+        else:
+            self.send = torch.zeros((self.pad_rows, w), dtype=torch.int32, device=self.device)
+            if self.rank == dst:
+                # one contiguous buffer; gather_list entries are views of it so that a single
+                # kernel can scatter all parts into the image
+                self.recv_all = torch.empty((self.world, self.pad_rows, w), dtype=torch.int32, device=self.device)
+                self.recv = [self.recv_all[p] for p in range(self.world)]
 
     def render(self, events=None):
         """One frame.  Returns the full image tensor on rank dst, None elsewhere.  `events`:
@@ -86,21 +97,19 @@ class ShardedRenderer:
         if events is not None:
             events[1].record()
         if self.world == 1:
-            self._assemble([self.send])
             return self.image
         dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
-        self._assemble(self.recv)
+        self._assemble()
         return self.image
 
-    def _assemble(self, parts):
-        for p, t in enumerate(parts):
+    def _assemble(self):
+        if self.image.is_cuda and hasattr(self.render_part, "place_all"):
+            self.render_part.place_all(self.world, self.pad_rows, self.recv_all, self.image)
+            return
+        for p in range(self.world):
             n = api.part_rows(self.h, p, self.world)
-            if n == 0:
-                continue
-            if self.image.is_cuda and hasattr(self.render_part, "place"):
-                self.render_part.place(p, self.world, t, self.image)
-            else:
+            if n:
                 idx = torch.as_tensor(tile_rows(self.h, p, self.world), device=self.image.device)
-                self.image[idx] = t[:n]
+                self.image[idx] = self.recv_all[p, :n]

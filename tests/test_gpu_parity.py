@@ -268,6 +268,26 @@ def test_parts_assemble_to_the_full_image(R, ctx, variant, nparts):
     assert int((image.cpu().numpy() != want).sum()) == 0
 
 
+@pytest.mark.parametrize("nparts", [2, 5, 8])
+def test_stacked_parts_assemble_in_one_kernel(R, ctx, nparts):
+    """rt_place_parts: what rank 0 runs on the gathered, padded send buffers of all ranks."""
+    import torch
+    from raytracers_amd.dist import max_part_rows
+    ctx.set_variant(0)
+    h, w = 211, 88
+    ps = R.prepare_scene(h, w, ctx.rgbbox())
+    want, _ = _oracle("rgbbox").render(h, w)
+    pad = max_part_rows(h, nparts)
+    stacked = torch.full((nparts, pad, w), -7, dtype=torch.int32, device="cuda")
+    image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(nparts):
+        R.render_into(stacked[p].data_ptr(), h, w, ps, part=p, nparts=nparts)
+    R.place_parts(ctx, h, w, nparts, pad, stacked.data_ptr(), image.data_ptr())
+    ctx.sync()
+    assert int((image.cpu().numpy() != want).sum()) == 0
+
+
 def test_sharded_renderer_single_rank_on_torch_stream(R):
     import torch
     from raytracers_amd.dist import HipPartRenderer, ShardedRenderer

@@ -249,8 +249,10 @@ struct Slot {
 };
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffu;  // (1e9, none)
 
+constexpr int kMaxSlots = 256;
+static int g_nslots = 64;   // ray slots per wave (the kernel has 64; what would more buy?)
 struct PWave {
-  Slot slot[64];
+  Slot slot[kMaxSlots];
   std::vector<unsigned> box, leaf;
   unsigned q_next = 0, q_end = 0;
   bool exhausted = false, done = false;
@@ -273,7 +275,8 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
   else if (nleaf >= (size_t)width) op = 1;
   else {
     int ndone = 0, nfree = 0;
-    for (auto &s : W.slot) {
+    for (int l = 0; l < g_nslots; ++l) {
+      auto &s = W.slot[l];
       if (s.active && s.cnt == 0) ndone++;
       if (!s.active && !W.exhausted) nfree++;
     }
@@ -291,15 +294,15 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
     C.lanes[0] += n;
     for (size_t k = 0; k < n; ++k) {
       const unsigned it = items[n - 1 - k];
-      const int sl = it >> 26, ni = it & 0x3ffffff;
+      const int sl = it >> 24, ni = it & 0xffffff;
       Slot &s = W.slot[sl];
       const rt::TravNode &nd = S.nodes[ni];
       C.box++;
       if (box_hit(s.r, nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0], nd.hi[1], nd.hi[2])) {
         const int kids[2] = {nd.left, nd.right};
         for (int c : kids) {
-          if (c < 0) W.leaf.push_back(((unsigned)sl << 26) | (unsigned)~c);
-          else W.box.push_back(((unsigned)sl << 26) | (unsigned)c);
+          if (c < 0) W.leaf.push_back(((unsigned)sl << 24) | (unsigned)~c);
+          else W.box.push_back(((unsigned)sl << 24) | (unsigned)c);
         }
         s.cnt += 1;
       } else
@@ -313,7 +316,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
     for (size_t k = 0; k < n; ++k) {
       const unsigned it = W.leaf.back();
       W.leaf.pop_back();
-      const int sl = it >> 26, j = it & 0x3ffffff;
+      const int sl = it >> 24, j = it & 0xffffff;
       Slot &s = W.slot[sl];
       const F4 &sp = S.sph[j];
       C.sphere++;
@@ -325,7 +328,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
       s.cnt -= 1;
     }
   } else {
-    for (int l = 0; l < 64; ++l) {
+    for (int l = 0; l < g_nslots; ++l) {
       Slot &s = W.slot[l];
       if (s.active && s.cnt == 0) {
         C.lanes[2]++;
@@ -336,7 +339,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
         int32_t pixel;
         if (finish_ray(s.r, best, bestj, sp.x, sp.y, sp.z, sp.w, c.x, c.y, c.z, c.w, s.lr, s.lg, s.lb, s.depth, S.max_depth, &pixel)) {
           s.key = kKeyInit; s.cnt = 1;
-          W.box.push_back(((unsigned)l << 26) | 0u);
+          W.box.push_back(((unsigned)l << 24) | 0u);
           C.rays++;
         } else {
           out[s.pix] = pixel;
@@ -344,7 +347,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
         }
       }
     }
-    for (int l = 0; l < 64 && !W.exhausted; ++l) {
+    for (int l = 0; l < g_nslots && !W.exhausted; ++l) {
       Slot &s = W.slot[l];
       if (s.active) continue;
       for (;;) {
@@ -363,7 +366,7 @@ static bool pwave_step(PWave &W, const SceneData &S, int width, int thr_shade, u
           s.r = primary_ray(S.cam, col, row, S.w, S.h);
           s.lr = s.lg = s.lb = 1.0f; s.depth = 0; s.pix = row * S.w + col; s.active = true;
           s.key = kKeyInit; s.cnt = 1;
-          W.box.push_back(((unsigned)l << 26) | 0u);
+          W.box.push_back(((unsigned)l << 24) | 0u);
           C.rays++;
           break;
         }
@@ -393,7 +396,7 @@ static int run_pooled(const SceneData &S, const std::vector<int32_t> &ref, int n
   const char *names[3] = {"BOX", "LEAF", "SHADE"};
   for (int i = 0; i < 3; ++i)
     std::printf("  %-5s wave-ops %10llu lanes %12llu efficiency %.3f\n", names[i], C.ops[i], C.lanes[i],
-                C.ops[i] ? (double)C.lanes[i] / ((i == 2 ? 64.0 : (double)width) * C.ops[i]) : 0.0);
+                C.ops[i] ? (double)C.lanes[i] / ((i == 2 ? (double)g_nslots : (double)width) * C.ops[i]) : 0.0);
   std::printf("  rounds (longest wave, in phases) %llu  max box stack %zu  max leaf list %zu\n", rounds, C.max_box, C.max_leaf);
   return diff ? 1 : 0;
 }
@@ -448,6 +451,7 @@ int main(int argc, char **argv) {
 
   if (P.kind >= 10) {
     // pooled design: kind 10 -> 64 items per op, kind 11 -> 128 items per op
+    if (P.lmax >= 64) g_nslots = P.lmax;   // reuse the lmax argument: slots per wave
     return run_pooled(S, ref, nwaves, P.kind == 11 ? 128 : 64, P.thr_shade);
   }
   std::vector<Wave> waves(nwaves);
