@@ -119,8 +119,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or bool(os.environ.get("RT_FORCE_GATHER"))   # the latter: exercise RCCL on one GPU
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
@@ -159,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -172,7 +174,7 @@ def main():
             step(k, ev[k], nlanes)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_pg:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -238,7 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

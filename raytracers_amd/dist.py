@@ -10,6 +10,8 @@ the same scene description.
 One process per GPU (torch.distributed); the renderer of a part is injected so that the
 sharding/gather logic is testable on CPU with the gloo backend.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -78,7 +80,10 @@ class ShardedRenderer:
         self.image = None
         if self.rank == dst:
             self.image = torch.empty((h, w), dtype=torch.int32, device=self.device)
-        if self.world == 1:
+        # RT_FORCE_GATHER=1 keeps the gather + assembly path on even for a single rank (used to
+        # exercise the RCCL path on a one-GPU box)
+        self.direct = self.world == 1 and not (dist.is_initialized() and os.environ.get("RT_FORCE_GATHER"))
+        if self.direct:
             self.send = self.image            # one part == the whole image: nothing to gather or assemble
         else:
             self.send = torch.zeros((self.pad_rows, w), dtype=torch.int32, device=self.device)
@@ -96,7 +101,7 @@ class ShardedRenderer:
         self.render_part(self.rank, self.world, self.send)
         if events is not None:
             events[1].record()
-        if self.world == 1:
+        if self.direct:
             return self.image
         dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
