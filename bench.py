@@ -95,6 +95,11 @@ def cpu_baseline(frames, budget_s=12.0):
 
 
 def main():
+    # Only the JSON line may appear on stdout: RCCL (and others) print banners to the C-level
+    # stdout, so fd 1 points at stderr for the whole run and is restored for the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -239,10 +244,16 @@ def main():
                                   / (skms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS for i, (sc, h, w) in enumerate(frames)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
