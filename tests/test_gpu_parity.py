@@ -386,3 +386,48 @@ def test_native_bench_runs(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     want, _ = _oracle("irreg").render(160, 120)
     assert int((_read_ppm(ppm) != want).sum()) == 0
+
+
+# ---------------------------------------------------------------- error behaviour ---------
+def test_errors_are_codes_with_messages(R, ctx):
+    """Every entry returns non-zero on failure and leaves a message (the reference's harness
+    convention is `assert(ret == 0)`, futhark/main.c:74,97,116,131); nothing is written then."""
+    import torch
+    ps = R.prepare_scene(32, 48, ctx.rgbbox())
+    out = torch.full((32, 48), 123, dtype=torch.int32, device="cuda")
+    with pytest.raises(R.RtError, match="prepared for"):       # the camera aspect is fixed by prepare_scene
+        R.render_into(out.data_ptr(), 48, 32, ps)
+    with pytest.raises(R.RtError, match="partition"):
+        R.render_into(out.data_ptr(), 32, 48, ps, part=3, nparts=3)
+    with pytest.raises(R.RtError, match="null"):
+        R.render_into(0, 32, 48, ps)
+    with pytest.raises(R.RtError, match="depth"):
+        R.render_into(out.data_ptr(), 32, 48, ps, max_depth=-1)
+    with pytest.raises(R.RtError, match="unknown option"):
+        ctx.set_option("no_such_knob", 1)
+    with pytest.raises(R.RtError, match="at least 2|2 \\.\\."):
+        R.prepare_scene(8, 8, ctx.scene_from_spheres(np.zeros((1, 7), np.float32) + 1, (0, 0, 5), (0, 0, 0), 60.0))
+    ctx.sync()
+    assert int((out.cpu().numpy() != 123).sum()) == 0
+    # and the context is still usable afterwards
+    want, _ = _oracle("rgbbox").render(32, 48)
+    assert int((R.render(32, 48, ps) != want).sum()) == 0
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_odd_rows_per_tile_on_the_non_pooled_families(R, ctx, variant):
+    """rows_per_tile need not be a power of two for the pixel / persistent families."""
+    import torch
+    ctx.set_variant(variant)
+    h, w, rpt, nparts = 77, 40, 5, 3
+    ps = R.prepare_scene(h, w, ctx.irreg())
+    want, _ = _oracle("irreg").render(h, w)
+    image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+    for p in range(nparts):
+        rows = R.part_rows(h, p, nparts, rows_per_tile=rpt)
+        part = torch.empty((max(rows, 1), w), dtype=torch.int32, device="cuda")
+        R.render_into(part.data_ptr(), h, w, ps, part=p, nparts=nparts, rows_per_tile=rpt)
+        R.place_part(ctx, h, w, p, nparts, part.data_ptr(), image.data_ptr(), rows_per_tile=rpt)
+    ctx.sync()
+    torch.cuda.synchronize()
+    assert int((image.cpu().numpy() != want).sum()) == 0
