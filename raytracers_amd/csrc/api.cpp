@@ -39,6 +39,7 @@ struct rt_context {
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
+  int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
@@ -224,6 +225,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
   p.prio_depth = ctx->prio_depth;
+  p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -361,6 +363,12 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_scene_bytes = v;
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
+  } else if (k == "low_box") {
+    ctx->low_box = std::max(0, std::min(64, v));
+  } else if (k == "thr_shade_low") {
+    ctx->thr_shade_low = std::max(1, std::min(64, v));
+  } else if (k == "low_leaf") {
+    ctx->low_leaf = std::max(1, std::min(64, v));
   } else if (k == "prio_depth") {
     ctx->prio_depth = std::max(0, v);
   } else if (k == "gpu_build") {
@@ -401,7 +409,7 @@ extern "C" int rt_scene_floor(rt_context *ctx, rt_scene **out, int n, float k) {
 extern "C" int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7, int64_t n,
                                      const float look_from[3], const float look_at[3], float fov) {
   if (!spheres7 || !look_from || !look_at) return fail(ctx, "null argument");
-  if (n < 2 || n > (int64_t(1) << 27)) return fail(ctx, "scene needs 2 .. 2^27 spheres");
+  if (n < 2 || n > (int64_t(1) << 26)) return fail(ctx, "scene needs 2 .. 2^26 spheres");
   rt::SceneDesc d;
   d.spheres.resize(static_cast<size_t>(n));
   std::memcpy(d.spheres.data(), spheres7, sizeof(rt::Sphere) * static_cast<size_t>(n));
@@ -449,7 +457,7 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   auto put = [&](void *dst, const void *src, size_t bytes) {
     if (!rc && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, "hipMemcpyAsync failed");
   };
-  if (ctx->gpu_build && n < (size_t(1) << 27)) {
+  if (ctx->gpu_build) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
     float *sph7 = nullptr;
     rc |= upload(ctx, &sph7, scene->desc.spheres.data(), n * sizeof(rt::Sphere));
@@ -633,6 +641,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl;
   p.prio_depth = ctx->prio_depth;
+  p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {

@@ -370,7 +370,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const bool vacant = (pix < 0) & !exhausted;
       const int ns = __popcll(bal(done | vacant));
-      if (ns >= p.thr_shade || (nbox | nleaf) == 0) {
+      // a short box stack means idle lanes in the coming BOX operations: be more eager to start
+      // new folds then (thr_shade_low applies while nbox < low_box)
+      const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
+      if (ns >= thr || (nbox | nleaf) == 0) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         continue;
       }
     }
-    if (nleaf >= 64 || nbox == 0) {
+    if (nleaf >= 64 || nbox == 0 || (nbox < p.low_box && nleaf >= p.low_leaf)) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;

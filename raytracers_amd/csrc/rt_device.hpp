@@ -38,6 +38,7 @@ struct KParams {
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
+  int low_box, thr_shade_low, low_leaf;   // policy while the box stack is short (see pooled_kernel)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [nchunks] ticket -> tile (nullptr: identity)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
