@@ -135,16 +135,27 @@ def main():
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
     S = max(1, args.frames_in_flight)
+    # With several frames in flight a launch need not fill the machine by itself: a quarter of
+    # the persistent workgroups per launch gives longer-lived, better-filled waves (its longer
+    # tail is hidden by the other frames).  One frame at a time keeps the library default.
+    opts_pipe = dict(opts)
+    if S >= 4 and args.variant in (0, 3):
+        opts_pipe.setdefault("grid_div", 4)
     # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
+
+    def make_lane(o):
+        lane = []
+        for scene, h, w in frames:
+            pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=o)
+            lane.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
+        return lane
+
     lanes = []
     for st in streams:
         with torch.cuda.stream(st):
-            lane = []
-            for scene, h, w in frames:
-                pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=opts)
-                lane.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
-            lanes.append(lane)
+            lanes.append(make_lane(opts_pipe))
+    serial_lane = make_lane(opts) if (S > 1 and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
     renderers = lanes[0]
 
@@ -159,6 +170,10 @@ def main():
         work[(scene, h, w)] = got
 
     def step(k, events=None, nlanes=S):
+        if nlanes == 0:       # the one-frame-at-a-time lane (library defaults, default stream)
+            for i, (_, _, _, _, sr) in enumerate(serial_lane):
+                sr.render(events[i] if events is not None else None)
+            return
         li = k % nlanes
         with torch.cuda.stream(streams[li]):
             for i, (_, _, _, _, sr) in enumerate(lanes[li]):
@@ -191,8 +206,10 @@ def main():
         step(k)
     elapsed, kern_ms = timed(args.steps, S)
     serial = None
-    if S > 1 and not args.no_serial_extra:
-        serial = timed(max(10, args.steps // 2), 1)
+    if serial_lane is not None:
+        for k in range(3):
+            step(k, None, 0)
+        serial = timed(max(10, args.steps // 2), 0)
 
     if rank == 0:
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
@@ -217,7 +234,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
-                       "options": opts, "frames_in_flight": S,
+                       "options": opts_pipe, "frames_in_flight": S,
                        "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
                          + f" on {dscene} {dw}x{dh}",

@@ -39,6 +39,7 @@ struct rt_context {
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
+  int grid_div = 1;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups
   int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   // ticket counter of the persistent family: monotonic across launches, never reset.
@@ -175,7 +176,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   pl->lds_sph = ls;
   pl->lds_bytes = pl->variant == RT_VARIANT_POOLED ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
                                                    : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
-  pl->grid = ctx->num_cu * ctx->wgs_per_cu;
+  pl->grid = std::max(1, ctx->num_cu * ctx->wgs_per_cu / std::max(1, ctx->grid_div));
   return 0;
 }
 
@@ -363,6 +364,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_scene_bytes = v;
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
+  } else if (k == "grid_div") {
+    ctx->grid_div = std::max(1, std::min(64, v));
   } else if (k == "low_box") {
     ctx->low_box = std::max(0, std::min(64, v));
   } else if (k == "thr_shade_low") {
