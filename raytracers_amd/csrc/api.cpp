@@ -158,7 +158,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
   pl->capb = 64 * (ps->height + 3);
   pl->capl = 256;
-  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl + 3 * 128) * 4
+  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl) * 4
                                                        : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
   int budget = total - scratch - 512;
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);

@@ -139,34 +139,24 @@ RT_HD int32_t pack_pixel(float r, float g, float b) {   // colour_to_pixel, ray.
   return (ir << 16) | (ig << 8) | ib;
 }
 
-// sphere_hit's quadratic in two steps (ray.fut:32-38): the discriminant ...
-RT_HD float sphere_disc(const Ray &r, float px, float py, float pz, float rad, float *b_out) {
+// sphere_root plus what the later re-intersection needs to know: *near_root is set when the
+// fold took root2 (root1 <= 0.1) although root1 > 0 -- exactly the case in which
+// `sphere_hit s r 0.0 (t+1)` (ray.fut:83-85) returns root1 instead of the fold's t.
+RT_HD float sphere_root_flag(const Ray &r, float px, float py, float pz, float rad, bool *near_root) {
   const float ocx = r.ox - px, ocy = r.oy - py, ocz = r.oz - pz;
   const float b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
   const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - rad * rad;
-  *b_out = b;
-  return b * b - r.a * c;
-}
-// ... and, for disc > 0, the root closest_hit would accept (see sphere_root).  *near_root is
-// set when the fold took root2 (root1 <= 0.1) although root1 > 0 -- exactly the case in which
-// `sphere_hit s r 0.0 (t+1)` (ray.fut:83-85) returns root1 instead of the fold's t.
-RT_HD float sphere_roots(float a, float b, float disc, bool *near_root) {
+  const float disc = b * b - r.a * c;
   *near_root = false;
+  if (disc <= 0.0f) return kNoHit;
   const float sq = sqrtf(disc);
-  float t = (-b - sq) / a;
+  float t = (-b - sq) / r.a;
   if (!(t > kEps)) {
     *near_root = t > 0.0f;
-    t = (-b + sq) / a;
+    t = (-b + sq) / r.a;
     if (!(t > kEps)) return kNoHit;
   }
   return t;
-}
-RT_HD float sphere_root_flag(const Ray &r, float px, float py, float pz, float rad, bool *near_root) {
-  float b;
-  const float disc = sphere_disc(r, px, py, pz, rad, &b);
-  *near_root = false;
-  if (disc <= 0.0f) return kNoHit;
-  return sphere_roots(r.a, b, disc, near_root);
 }
 
 // The literal re-intersection of the winning sphere, `sphere_hit s r 0.0 (best+1)`

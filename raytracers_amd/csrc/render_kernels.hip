@@ -304,7 +304,6 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // 64 items per "generation" with strictly increasing depth labels => size <= 64*H + 128.
 // The leaf list is drained first whenever it holds >= 64 items => size <= 63 + 128.
 // ---------------------------------------------------------------------------------
-constexpr int kRootCap = 128;   // root list entries per wave: drained at 64, a LEAF operation adds <= 64
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
 __device__ __forceinline__ float pull(int lane_byte, float v) {
@@ -323,16 +322,14 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sph_base = 4 * p.lds_nodes;   // 64-byte node records = 4 x float4
-  // per-wave region: key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl] |
-  //                  root list: item[kRootCap] b[kRootCap] disc[kRootCap]
-  const int per_wave_dw = 128 + 64 + 4 + p.capb + p.capl + 3 * kRootCap;
+  // per-wave region: key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl]
+  const int per_wave_dw = 128 + 64 + 4 + p.capb + p.capl;
   unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
   unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
   int *const wcnt = reinterpret_cast<int *>(wbase + 128);
   unsigned *const wdump = wbase + 192;    // where lanes with nothing to append write
   unsigned *const wbox = wbase + 196;
   unsigned *const wleaf = wbox + p.capb;
-  unsigned *const wroot = wleaf + p.capl;   // (slot, leaf) items whose discriminant is positive: sqrt + divisions pending
   const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
 
@@ -351,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int pix = -1;            // -1: slot empty
   unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
   // ---- wave state (uniform) ----
-  int nbox = 0, nleaf = 0, nroot = 0;
+  int nbox = 0, nleaf = 0;
   unsigned q_next = 0, q_end = 0;
   int q_tile = 0;          // tile the current ticket maps to
   int q_col0 = 0, q_row0 = 0;   // its first pixel column / local row
@@ -368,27 +365,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
     nbox = __builtin_amdgcn_readfirstlane(nbox);
     nleaf = __builtin_amdgcn_readfirstlane(nleaf);
-    nroot = __builtin_amdgcn_readfirstlane(nroot);
-    if (nroot >= 64 || (nroot > 0 && nbox == 0 && nleaf == 0)) {
-      // ---- ROOT: up to 64 leaf tests whose discriminant is positive: sqrt, divisions, min ----
-      const int top = nroot - 1 - lane;
-      const int idx = top < 0 ? 0 : top;
-      const unsigned item = wroot[idx];
-      const float b = __uint_as_float(wroot[kRootCap + idx]), disc = __uint_as_float(wroot[2 * kRootCap + idx]);
-      const bool act = top >= 0;
-      nroot = nroot > 64 ? nroot - 64 : 0;
-      const int sl4 = (int)(item & 0xfcu);
-      const int jj = act ? ~((int)item >> 8) : 0;
-      const float a = pull(sl4, r.a);
-      bool near_root;
-      const float g = sphere_roots(a, b, disc, &near_root);
-      // key = (bits(t), leaf << 1 | near_root): min = smallest t, ties to the lowest leaf
-      if (act & (g < kTMax))
-        atomicMin(&wkey[sl4 >> 2],
-                  ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
-      atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);
-      continue;
-    }
     if (nbox < 64 && nleaf < 64) {
       // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
@@ -397,7 +373,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       // a short box stack means idle lanes in the coming BOX operations: be more eager to start
       // new folds then (thr_shade_low applies while nbox < low_box)
       const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
-      if (ns >= thr || (nbox | nleaf | nroot) == 0) {
+      if (ns >= thr || (nbox | nleaf) == 0) {
         if (ns == 0) break;
         // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
         bool root = false;
@@ -519,21 +495,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         if (jj >= p.lds_sph) s = buf_load16(rs_sph, jj * 16);
       }
       if (STATS) n_sph += act ? 1 : 0;
-      // first half of sphere_hit: ~2/3 of the tests end here (discriminant <= 0).  The others
-      // move to the root list with b and the discriminant, so that the square root and the
-      // divisions run on full waves of survivors instead of inside every LEAF operation.
-      float b;
-      const float disc = sphere_disc(q, s.x, s.y, s.z, s.w, &b);
-      const unsigned long long m_act = bal(top >= 0);
-      const unsigned long long m_pos = m_act & bal(disc > 0.0f);
-      // (the last entry of the three root arrays is their dump slot: the list holds <= 63 + 64 entries)
-      const int a_root = sel_mask(m_pos, (int)(size_t)(wroot + kRootCap - 1), (int)(size_t)(wroot + nroot) + 4 * lane_rank(m_pos));
-      lds_store(a_root, item);
-      lds_store(a_root + 4 * kRootCap, __float_as_uint(b));
-      lds_store(a_root + 8 * kRootCap, __float_as_uint(disc));
-      nroot += __popcll(m_pos);
-      // a test that ends here retires its item; a survivor's item lives on in the root list
-      atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_act & ~m_pos, 0, -1));
+      bool near_root;
+      const float g = sphere_root_flag(q, s.x, s.y, s.z, s.w, &near_root);
+      // key = (bits(t), leaf << 1 | near_root): min = smallest t, ties to the lowest leaf
+      if (act & (g < kTMax))
+        atomicMin(&wkey[sl4 >> 2],
+                  ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
+      atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
       if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
@@ -746,7 +714,7 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
 }
 
 size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg) {
-  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (196 + capb + capl + 3 * kRootCap) * sizeof(unsigned);
+  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (196 + capb + capl) * sizeof(unsigned);
 }
 
 template <int THREADS, bool ALL_LDS, bool STATS>
