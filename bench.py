@@ -89,9 +89,25 @@ def cpu_baseline(frames, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s or reps >= 5:
             break
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} full frame(s) of each of {'+'.join(f'{s} {w}x{h}' for s, h, w in frames)}, "
-                      f"OpenMP dynamic over rows on all {cores} host threads, {dt:.1f} s"}
+    out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} full frame(s) of each of {'+'.join(f'{s} {w}x{h}' for s, h, w in frames)}, "
+                     f"OpenMP dynamic over rows on all {cores} host threads, {dt:.1f} s"}
+    # second comparator: the reference's RUST algorithm (different BVH / epsilon, different image;
+    # timing only -- oracle/rust_algo_port.c), same frames, same threads
+    try:
+        rs = [(O.RustAlgoScene(s), h, w) for s, h, w in frames if s in ("rgbbox", "irreg")]
+        if rs:
+            rrays, t1 = 0, time.perf_counter()
+            for _ in range(2):
+                for sc, h, w in rs:
+                    rrays += sc.render(h, w, threads=0)[1]
+            rdt = time.perf_counter() - t1
+            out["rust_algorithm"] = {"value": rrays / rdt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+                                     "sample": f"2 frames of each scene, {rdt:.1f} s",
+                                     "note": "C restatement of rust/src/lib.rs (median-split BVH, eps 0.001): timing only"}
+    except Exception as e:   # the baseline must never take the bench line down
+        out["rust_algorithm"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -252,6 +268,15 @@ def main():
             "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
                                   "note": "README.md:50 render times / oracle ray counts; different hardware"},
         }
+        # measured HBM traffic of that launch: PMC counters cannot be collected inside this run; the
+        # figure comes from the committed PMC passes (profiles/traffic.json, tools/gpu_pmc.sh)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tr = json.load(f).get(f"pooled_kernel {dscene} {dw}x{dh}")
+            if tr and args.variant in (0, 3) and world == 1:
+                out["roofline"]["traffic"] = tr["hbm_bytes"]
+        except (OSError, ValueError):
+            pass
         if serial is not None:
             sdt, skms = serial
             out["roofline"]["frac_one_frame_at_a_time"] = (bytes_alg(work[frames[dom]][1], work[frames[dom]][2], dh, dw) / world

@@ -55,8 +55,8 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(ORACLE_DIR, "ray_oracle.c")
-        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("ray_oracle.c", "rust_algo_port.c")]
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
             build()
         L = C.CDLL(LIB_PATH)
         L.orc_scene_rgbbox.argtypes = [C.POINTER(Scene)]
@@ -71,6 +71,9 @@ def lib():
         L.orc_checksum.argtypes = [C.c_void_p, C.c_int64]
         L.orc_checksum.restype = C.c_uint32
         L.orc_num_threads.restype = C.c_int
+        L.rust_bvh_build.argtypes = [C.POINTER(Sphere), C.c_int64, C.c_void_p]
+        L.rust_bvh_free.argtypes = [C.c_void_p]
+        L.rust_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -156,6 +159,29 @@ class OracleScene:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class RustAlgoScene:
+    """The reference's RUST algorithm (oracle/rust_algo_port.c): a second CPU baseline for
+    timing only -- it renders a different image than the Futhark program."""
+
+    def __init__(self, name):
+        self.base = OracleScene(name)
+        self.bvh = (C.c_char * 64)()
+        assert lib().rust_bvh_build(self.base.scene.spheres, self.base.scene.n, C.byref(self.bvh)) == 0
+
+    def render(self, h, w, threads=0):
+        out = np.empty((h, w), dtype=np.int32)
+        cam = self.base.camera_floats(h, w)
+        rays = C.c_uint64()
+        assert lib().rust_render(C.byref(self.bvh), cam.ctypes.data, w, h, threads, out.ctypes.data, C.byref(rays)) == 0
+        return out, int(rays.value)
+
+    def __del__(self):
+        try:
+            lib().rust_bvh_free(C.byref(self.bvh))
         except Exception:
             pass
 

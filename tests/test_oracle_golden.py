@@ -80,3 +80,13 @@ def test_bvh_structure_invariants():
         for side in ("left", "right"):
             idx = np.nonzero(A[side] >= 0)[0]
             assert (A["parent"][A[side][idx]] == idx).all()
+
+
+def test_rust_algorithm_port_is_a_plausible_renderer():
+    """oracle/rust_algo_port.c is a timing-only baseline (the Rust variant traces a different
+    image: other BVH, epsilon 0.001); it must still be *a* correct ray tracer of the same scene."""
+    for name in ("rgbbox", "irreg"):
+        px, rays = O.RustAlgoScene(name).render(200, 200)
+        ref, cnt = O.OracleScene(name).render(200, 200)
+        assert (px == ref).mean() > 0.97
+        assert abs(rays - cnt["rays"]) < 0.02 * cnt["rays"]
