@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -332,6 +333,15 @@ extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->
 
 extern "C" int rt_context_sync(rt_context *ctx) {
   if (!ctx) return 1;
+  // Frames take well under a millisecond: poll for a while before falling back to the blocking
+  // wait (whose wake-up latency alone is a sizeable fraction of a frame).
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+  }
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }

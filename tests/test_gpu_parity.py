@@ -431,3 +431,24 @@ def test_odd_rows_per_tile_on_the_non_pooled_families(R, ctx, variant):
     ctx.sync()
     torch.cuda.synchronize()
     assert int((image.cpu().numpy() != want).sum()) == 0
+
+
+# ---------------------------------------------------------------- the bench contract ------
+def test_bench_line_contract(tmp_path):
+    """bench.py prints exactly ONE line on stdout, a JSON object with the keys the driver reads."""
+    import json
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "Mray/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["higher_is_better"] is True
+    assert d["value"] > 100 and "workload" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
