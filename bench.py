@@ -138,13 +138,21 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # RT_SHARE_GPU=1: every rank uses cuda:0 and the gloo backend (host-staged gather) -- a test
+    # mode that runs the multi-rank control flow on a one-GPU box; never the measured configuration
+    share_gpu = bool(os.environ.get("RT_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_pg = world > 1 or bool(os.environ.get("RT_FORCE_GATHER"))   # the latter: exercise RCCL on one GPU
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
 
@@ -251,7 +259,8 @@ def main():
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
                        "options": opts_pipe, "frames_in_flight": S,
-                       "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"},
+                       "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"
+                                    + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
             "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
                          + f" on {dscene} {dw}x{dh}",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

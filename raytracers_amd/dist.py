@@ -80,6 +80,11 @@ class ShardedRenderer:
         self.image = None
         if self.rank == dst:
             self.image = torch.empty((h, w), dtype=torch.int32, device=self.device)
+        # A CPU-only backend (gloo) cannot move device memory: stage the gather through host
+        # buffers then.  Only used to exercise the multi-rank control flow on a one-GPU box
+        # (several ranks sharing cuda:0); the product path is backend "nccl" = RCCL over xGMI.
+        self.host_staged = (self.device.type == "cuda" and dist.is_initialized()
+                            and dist.get_backend(group) == "gloo")
         # RT_FORCE_GATHER=1 keeps the gather + assembly path on even for a single rank (used to
         # exercise the RCCL path on a one-GPU box)
         self.direct = self.world == 1 and not (dist.is_initialized() and os.environ.get("RT_FORCE_GATHER"))
@@ -103,9 +108,17 @@ class ShardedRenderer:
             events[1].record()
         if self.direct:
             return self.image
-        dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
-        if self.rank != self.dst:
-            return None
+        if self.host_staged:
+            send_h = self.send.cpu()      # synchronises with the render on the current stream
+            recv_h = [torch.empty_like(send_h) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(send_h, recv_h, dst=self.dst, group=self.group)
+            if self.rank != self.dst:
+                return None
+            self.recv_all.copy_(torch.stack(recv_h))
+        else:
+            dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            if self.rank != self.dst:
+                return None
         self._assemble()
         return self.image
 

@@ -452,3 +452,47 @@ def test_bench_line_contract(tmp_path):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+
+
+# ---------------------------------------------------------------- multi-rank on one GPU ---
+def _rank_worker(rank, world, port, scene, h, w, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
+        torch.cuda.set_device(0)
+        pr = HipPartRenderer(scene, h, w, "cuda:0")
+        sr = ShardedRenderer(pr, h, w, device="cuda:0")
+        for _ in range(3):
+            img = sr.render()
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put(img.cpu().numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_render_sharing_one_gpu(world):
+    """Several ranks (processes) share cuda:0: each renders its cyclic row tiles with the HIP
+    library, rank 0 gathers (gloo, host-staged -- the one-GPU stand-in for RCCL) and assembles
+    with rt_place_parts.  The image must equal the single-GPU / oracle image."""
+    import torch.multiprocessing as mp
+    h, w, scene = 171, 120, "irreg"
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29600 + (os.getpid() % 1000) + world
+    procs = [ctxm.Process(target=_rank_worker, args=(r, world, port, scene, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    img = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    want, _ = _oracle(scene).render(h, w)
+    assert int((img != want).sum()) == 0
