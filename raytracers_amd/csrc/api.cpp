@@ -55,6 +55,14 @@ struct rt_context {
     float *u, *v;
   };
   std::vector<UvTable> uv;
+  // Freed device blocks kept for the next prepare_scene (the reference's harness prepares the same
+  // scene `runs` times: hipMalloc / hipFree of a few MB cost more than the build itself).
+  struct Block {
+    char *p;
+    size_t bytes;
+  };
+  std::vector<Block> pool;
+  char *pinned = nullptr;  // host-pinned block the build kernels report through / read small scenes from
 };
 
 struct rt_scene {
@@ -84,6 +92,7 @@ struct rt_prepared {
   // traversal copy
   float4 *nodes = nullptr, *nodes64 = nullptr, *sph = nullptr, *col = nullptr;
   char *block = nullptr;   // one device allocation behind all of the arrays above
+  size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
 };
 
@@ -101,6 +110,38 @@ int hip_fail(rt_context *ctx, hipError_t e, const char *what) {
     hipError_t e_ = (call);                                      \
     if (e_ != hipSuccess) return hip_fail((ctx), e_, #call);     \
   } while (0)
+
+// ---- device-block pool -------------------------------------------------------------------------
+constexpr size_t kPoolMaxBlocks = 8, kPoolMaxBlockBytes = size_t(256) << 20;
+hipError_t pool_alloc(rt_context *ctx, char **out, size_t *bytes_io) {
+  const size_t want = (*bytes_io + 0xffff) & ~size_t(0xffff);   // 64 KiB granules make repeats hit
+  size_t best = ctx->pool.size();
+  for (size_t i = 0; i < ctx->pool.size(); ++i)
+    if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want &&
+        (best == ctx->pool.size() || ctx->pool[i].bytes < ctx->pool[best].bytes))
+      best = i;
+  if (best != ctx->pool.size()) {
+    *out = ctx->pool[best].p;
+    *bytes_io = ctx->pool[best].bytes;
+    ctx->pool.erase(ctx->pool.begin() + static_cast<long>(best));
+    return hipSuccess;
+  }
+  *bytes_io = want;
+  return hipMalloc(reinterpret_cast<void **>(out), want);
+}
+// (the caller has drained every stream that used the block)
+void pool_free(rt_context *ctx, char *p, size_t bytes) {
+  if (!p) return;
+  if (!ctx || bytes > kPoolMaxBlockBytes) {
+    (void)hipFree(p);
+    return;
+  }
+  if (ctx->pool.size() >= kPoolMaxBlocks) {
+    (void)hipFree(ctx->pool.front().p);
+    ctx->pool.erase(ctx->pool.begin());
+  }
+  ctx->pool.push_back({p, bytes});
+}
 
 template <class T>
 int upload(rt_context *ctx, T **dev, const void *host, size_t bytes) {
@@ -325,6 +366,8 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   }
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  for (auto &b : ctx->pool) (void)hipFree(b.p);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -459,7 +502,8 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     const size_t o_L7 = carve(n * 28), o_bmin = carve(ni * 12), o_bmax = carve(ni * 12), o_left = carve(ni * 4),
                  o_right = carve(ni * 4), o_parent = carve(ni * 4), o_nodes = carve(ni * 32), o_nodes64 = carve(ni * 64),
                  o_sph = carve(n * 16), o_col = carve(n * 16);
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ps->block), off));
+    ps->block_bytes = off;
+    RT_HIP(ctx, pool_alloc(ctx, &ps->block, &ps->block_bytes));
     char *b = ps->block;
     ps->L7 = reinterpret_cast<float *>(b + o_L7); ps->bmin = reinterpret_cast<float *>(b + o_bmin);
     ps->bmax = reinterpret_cast<float *>(b + o_bmax); ps->left = reinterpret_cast<int32_t *>(b + o_left);
@@ -472,20 +516,20 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   };
   if (ctx->gpu_build) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
-    float *sph7 = nullptr;
-    rc |= upload(ctx, &sph7, scene->desc.spheres.data(), n * sizeof(rt::Sphere));
-    if (!rc) {
+    size_t tmp_bytes = rtk::gpu_build_scratch_bytes(static_cast<int>(n));
+    char *tmp = nullptr;
+    e = pool_alloc(ctx, &tmp, &tmp_bytes);
+    if (e == hipSuccess && !ctx->pinned)
+      e = hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault);
+    if (e == hipSuccess) {
       rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
-      e = rtk::gpu_build_bvh(sph7, static_cast<int>(n), o, ctx->stream, &ps->height);
-      float root[8];
-      if (e == hipSuccess) e = hipMemcpyAsync(root, ps->nodes, sizeof root, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e == hipSuccess) {
-        std::copy(root, root + 3, ps->root_lo);
-        std::copy(root + 4, root + 7, ps->root_hi);
-      }
+      e = rtk::gpu_build_bvh(reinterpret_cast<const float *>(scene->desc.spheres.data()), static_cast<int>(n), o, tmp,
+                             ctx->pinned, ctx->stream, &ps->height, ps->root_lo, ps->root_hi);
     }
-    if (sph7) (void)hipFree(sph7);
+    if (tmp) {
+      (void)hipStreamSynchronize(ctx->stream);
+      pool_free(ctx, tmp, tmp_bytes);
+    }
   } else {
     const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
     const rt::TravLayout tl = rt::make_trav_layout(bvh);
@@ -519,7 +563,7 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  if (ps->block) (void)hipFree(ps->block);
+  pool_free(ctx, ps->block, ps->block_bytes);
   for (auto &o : ps->orders) {
     (void)hipFree(o.cost);
     (void)hipFree(o.order);

@@ -12,6 +12,9 @@
 // Everything is enqueued on the caller's stream; the only host round trips are the
 // "did any depth change" flag (once per 8 sweeps) and the final tree height.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdint>
@@ -109,10 +112,7 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
 }
 __device__ __forceinline__ unsigned quantise10(float q) { return (unsigned)f_min(f_max(q * 1024.0f, 0.0f), 1023.0f); }
 
-__global__ __launch_bounds__(kBT) void morton_kernel(const float *centres, const float *bounds, int n, unsigned *keys,
-                                                     int *vals) {
-  const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void morton_elem(int i, const float *centres, const float *bounds, unsigned *keys, int *vals) {
   unsigned code[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -123,13 +123,19 @@ __global__ __launch_bounds__(kBT) void morton_kernel(const float *centres, const
   keys[i] = code[0] * 4u + code[1] * 2u + code[2];
   vals[i] = i;
 }
+__global__ __launch_bounds__(kBT) void morton_kernel(const float *centres, const float *bounds, int n, unsigned *keys,
+                                                     int *vals) {
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i < n) morton_elem(i, centres, bounds, keys, vals);
+}
 
 // ---- stable LSD radix sort of (key, val), 2 bits per pass ---------------------------------
 // Thread t of a block owns kSortE CONSECUTIVE elements, so thread order == element order and a
 // block-wide exclusive scan of per-thread digit counts gives stable ranks.  Counts of the four
 // digit values travel packed in one u64 (16 bits each).
+template <int NT = kBT>
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total) {
-  __shared__ unsigned long long wave_sum[kBT / 64];
+  __shared__ unsigned long long wave_sum[NT / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long incl = v;
 #pragma unroll
@@ -141,7 +147,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
   __syncthreads();
   unsigned long long base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kBT / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     if (w < wave) base += wave_sum[w];
     tot += wave_sum[w];
   }
@@ -238,9 +244,7 @@ __device__ __forceinline__ int delta(const unsigned *L, int n, int i, int j) {
 }
 
 // ptr encoding of the canonical arrays: inner i -> i, leaf i -> -2 - i
-__global__ __launch_bounds__(kBT) void radix_tree_kernel(const unsigned *L, int n, int *left, int *right, int *parent) {
-  const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= n - 1) return;
+__device__ __forceinline__ void radix_tree_node(int i, const unsigned *L, int n, int *left, int *right, int *parent) {
   const int diff = delta(L, n, i, i + 1) - delta(L, n, i, i - 1);
   const int d = (diff > 0) - (diff < 0);
   const int dmin = delta(L, n, i, i - d);
@@ -270,12 +274,14 @@ __global__ __launch_bounds__(kBT) void radix_tree_kernel(const unsigned *L, int 
     parent[gamma + 1] = i;
   }
 }
+__global__ __launch_bounds__(kBT) void radix_tree_kernel(const unsigned *L, int n, int *left, int *right, int *parent) {
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i < n - 1) radix_tree_node(i, L, n, left, right, parent);
+}
 
 // ---- AABB propagation: one Jacobi sweep (bvh.fut:48-58) -----------------------------------
-__global__ __launch_bounds__(kBT) void aabb_sweep_kernel(const float *L7, const int *left, const int *right, int ni,
-                                                         const float *pmin, const float *pmax, float *cmin, float *cmax) {
-  const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= ni) return;
+__device__ __forceinline__ void aabb_sweep_node(int i, const float *L7, const int *left, const int *right,
+                                                const float *pmin, const float *pmax, float *cmin, float *cmax) {
   float mn[2][3], mx[2][3];
   const int kid[2] = {left[i], right[i]};
 #pragma unroll
@@ -301,6 +307,11 @@ __global__ __launch_bounds__(kBT) void aabb_sweep_kernel(const float *L7, const 
     cmin[3 * (size_t)i + a] = f_min(mn[0][a], mn[1][a]);   // enclosing, prim.fut:38-45
     cmax[3 * (size_t)i + a] = f_max(mx[0][a], mx[1][a]);
   }
+}
+__global__ __launch_bounds__(kBT) void aabb_sweep_kernel(const float *L7, const int *left, const int *right, int ni,
+                                                         const float *pmin, const float *pmax, float *cmin, float *cmax) {
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i < ni) aabb_sweep_node(i, L7, left, right, pmin, pmax, cmin, cmax);
 }
 
 // ---- node depths (for the traversal numbering) ----------------------------------------------
@@ -328,11 +339,8 @@ __global__ __launch_bounds__(kBT) void invert_kernel(const int *order, int ni, i
 }
 
 // ---- traversal copy ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const int *trav_of, const int *left,
-                                                         const int *right, const float *bmin, const float *bmax, int ni,
-                                                         float4 *nodes32, float4 *nodes64) {
-  const int t = blockIdx.x * kBT + threadIdx.x;
-  if (t >= ni) return;
+__device__ __forceinline__ void trav_node(int t, const int *order, const int *trav_of, const int *left, const int *right,
+                                          const float *bmin, const float *bmax, float4 *nodes32, float4 *nodes64) {
   const int c = order[t];
   const int kid[2] = {left[c], right[c]};
   int ref[2];
@@ -359,6 +367,12 @@ __global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const
   nodes32[2 * (size_t)t + 0] = make_float4(mn[0], mn[1], mn[2], __int_as_float(ref[0]));
   nodes32[2 * (size_t)t + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(ref[1]));
 }
+__global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const int *trav_of, const int *left,
+                                                         const int *right, const float *bmin, const float *bmax, int ni,
+                                                         float4 *nodes32, float4 *nodes64) {
+  const int t = blockIdx.x * kBT + threadIdx.x;
+  if (t < ni) trav_node(t, order, trav_of, left, right, bmin, bmax, nodes32, nodes64);
+}
 
 __global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int n, float4 *sph, float4 *col) {
   const int i = blockIdx.x * kBT + threadIdx.x;
@@ -366,6 +380,355 @@ __global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int 
   const float *s = L7 + 7 * (size_t)i;
   sph[i] = make_float4(s[0], s[1], s[2], s[6]);
   col[i] = make_float4(s[3], s[4], s[5], 1.0f / s[6]);
+}
+
+// ---- small scenes: the whole build in ONE workgroup, one launch ---------------------------------
+// For n <= kSmallMax everything above runs inside a single 1024-thread workgroup with
+// __syncthreads() between the phases (the reference scenes have 400 and 10 000 spheres: a chain
+// of ~125 tiny launches costs more in launch gaps than in work).  Same arithmetic, same arrays.
+// Sort keys/values, the sorted Morton keys (the radix tree's binary searches), parent links and
+// the traversal numbering live in LDS (2 x 4n bytes <= 128 KB); boxes stay in global memory (L2).
+constexpr int kSmallNT = 1024;
+constexpr int kSmallMax = 16384;   // digit totals fit the packed 16-bit counters
+constexpr int kSmallE = 17;        // consecutive elements a thread owns in a sort pass (odd: LDS stride)
+
+struct SmallArgs {
+  const float *sph7_in;   // [n][7] input, host-pinned (read once, streaming)
+  float *sph7;            // [n][7] device copy (the gather after the sort reads it)
+  int n, sweeps;
+  GpuBvhOut o;
+  float *centres;   // [n][3]
+  float4 *box4;     // [2][n-1][2]: ping-pong boxes {lo.xyz, final?} {hi.xyz, -}
+  int *order, *trav_of;   // [n-1] traversal numbering and its inverse
+  int *result;      // host-pinned: [0] max depth, [4..11] the root's traversal record
+};
+
+// inclusive add-scan across the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// Stable LSD sort of (lk[i], lv[i]), i < m, by key bits [0, bits): 2 bits per pass.  Thread t owns
+// elements [t*E, (t+1)*E) in registers between passes; LDS is the exchange buffer.  Digit counts
+// travel as four 16-bit fields (two per dword: m <= 16384, so no field ever carries).
+__device__ __forceinline__ void small_sort(unsigned *lk, unsigned *lv, int m, int bits) {
+  __shared__ uint2 wave_tot[2][kSmallNT / 64];
+  const int E = ((m + kSmallNT - 1) / kSmallNT) | 1;   // odd: conflict-free stride
+  const int base = threadIdx.x * E;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned k[kSmallE], v[kSmallE];
+#pragma unroll
+  for (int e = 0; e < kSmallE; ++e)
+    if (e < E && base + e < m) {
+      k[e] = lk[base + e];
+      v[e] = lv[base + e];
+    }
+  int par = 0;
+  for (int shift = 0; shift < bits; shift += 2, par ^= 1) {
+    unsigned c01 = 0, c23 = 0;   // counts of digits {0,1} and {2,3}
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < m) {
+        const unsigned d = (k[e] >> shift) & 3u;
+        const unsigned one = 1u << ((d & 1u) * 16);
+        c01 += d < 2 ? one : 0u;
+        c23 += d < 2 ? 0u : one;
+      }
+    const unsigned i01 = wave_incl_scan_add(c01), i23 = wave_incl_scan_add(c23);
+    if (lane == 63) wave_tot[par][wave] = make_uint2(i01, i23);
+    __syncthreads();   // (also: every thread's chunk is in registers before anyone scatters)
+    unsigned b01 = 0, b23 = 0, t01 = 0, t23 = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallNT / 64; ++w) {
+      const uint2 t = wave_tot[par][w];
+      b01 += w < wave ? t.x : 0u;
+      b23 += w < wave ? t.y : 0u;
+      t01 += t.x;
+      t23 += t.y;
+    }
+    // exclusive rank of this thread's first element of each digit, plus where the digit starts
+    const unsigned n0 = t01 & 0xffffu, n1 = t01 >> 16, n2 = t23 & 0xffffu;
+    unsigned r01 = b01 + i01 - c01 + (n0 << 16);
+    unsigned r23 = b23 + i23 - c23 + (n0 + n1) + ((n0 + n1 + n2) << 16);
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < m) {
+        const unsigned d = (k[e] >> shift) & 3u;
+        const unsigned sh = (d & 1u) * 16;
+        const unsigned pos = ((d < 2 ? r01 : r23) >> sh) & 0xffffu;
+        lk[pos] = k[e];
+        lv[pos] = v[e];
+        r01 += d < 2 ? 1u << sh : 0u;
+        r23 += d < 2 ? 0u : 1u << sh;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < m) {
+        k[e] = lk[base + e];
+        v[e] = lv[base + e];
+      }
+  }
+}
+
+__global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
+  extern __shared__ unsigned small_lds[];
+  __shared__ float s_red[kSmallNT / 64][6];
+  __shared__ float s_bounds[8];
+  __shared__ int s_maxdepth;
+  const int tid = threadIdx.x, n = a.n, ni = a.n - 1;
+  unsigned *lk = small_lds, *lv = small_lds + n;
+  // phase timestamps (100 MHz) for RT_BVH_STAMPS=1, written straight into the pinned result block
+  unsigned long long *stamps = (unsigned long long *)(a.result + 16);
+#define STAMP(k) do { if (tid == 0) stamps[k] = wall_clock64(); } while (0)
+  STAMP(0);
+  // 0. the input spheres come straight from host-pinned memory (one coalesced streaming read)
+  if (a.sph7_in != a.sph7) {
+    const float4 *in4 = (const float4 *)a.sph7_in;   // (both blocks are padded to whole float4s)
+    float4 *out4 = (float4 *)a.sph7;
+    const int n4 = (7 * n + 3) / 4;
+    for (int j0 = 0; j0 < n4; j0 += 8 * kSmallNT) {   // 8 loads in flight per lane: PCIe latency, not bandwidth
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u * kSmallNT + tid < n4) t[u] = in4[j0 + u * kSmallNT + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u * kSmallNT + tid < n4) out4[j0 + u * kSmallNT + tid] = t[u];
+    }
+  }
+  __syncthreads();
+  // 1. centres and their bounds
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += kSmallNT) {
+    float c[3];
+    sphere_centre(a.sph7 + 7 * (size_t)i, c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      a.centres[3 * (size_t)i + k] = c[k];
+      lo[k] = f_min(lo[k], c[k]);
+      hi[k] = f_max(hi[k], c[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[k] = f_min(lo[k], __shfl_xor(lo[k], o));
+      hi[k] = f_max(hi[k], __shfl_xor(hi[k], o));
+    }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s_red[tid >> 6][k] = lo[k];
+      s_red[tid >> 6][3 + k] = hi[k];
+    }
+  }
+  if (tid == 0) s_maxdepth = 0;
+  __syncthreads();
+  if (tid < 6) {
+    float r = s_red[0][tid];
+    for (int w = 1; w < kSmallNT / 64; ++w) r = tid < 3 ? f_min(r, s_red[w][tid]) : f_max(r, s_red[w][tid]);
+    s_bounds[tid] = r;
+  }
+  __syncthreads();
+  STAMP(1);
+  // 2. Morton keys (each thread reads back the centres it wrote)
+  for (int i = tid; i < n; i += kSmallNT) morton_elem(i, a.centres, s_bounds, lk, (int *)lv);
+  __syncthreads();
+  STAMP(2);
+  // 3. stable sort by the 30-bit key
+  small_sort(lk, lv, n, 30);
+  STAMP(3);
+  // 4. sorted spheres (canonical L, and the traversal copies of the same data)
+  for (int i = tid; i < n; i += kSmallNT) {
+    const float *s = a.sph7 + 7 * (size_t)lv[i];
+    float *d = a.o.L7 + 7 * (size_t)i;
+    float f[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) f[k] = s[k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d[k] = f[k];
+    a.o.sph[i] = make_float4(f[0], f[1], f[2], f[6]);
+    a.o.col[i] = make_float4(f[3], f[4], f[5], 1.0f / f[6]);
+  }
+  __syncthreads();
+  STAMP(4);
+  // 5. radix tree over the sorted keys (keys in lk; parent links into lv)
+  int *lpar = (int *)lv;
+  for (int i = tid; i < ni; i += kSmallNT) lpar[i] = -1;
+  __syncthreads();
+  for (int i = tid; i < ni; i += kSmallNT) radix_tree_node(i, lk, n, a.o.left, a.o.right, lpar);
+  __syncthreads();
+  STAMP(5);
+  // 6. depth of every inner node = number of ancestors; keys for the traversal numbering
+  {
+    const int E = ((ni + kSmallNT - 1) / kSmallNT) | 1;
+    const int base = tid * E;
+    int dep[kSmallE], md = 0;
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < ni) {
+        int d = 0;
+        for (int p = lpar[base + e]; p >= 0; p = lpar[p]) ++d;
+        dep[e] = d;
+        md = max(md, d);
+        a.o.parent[base + e] = lpar[base + e];
+      }
+    for (int o = 32; o > 0; o >>= 1) md = max(md, __shfl_xor(md, o));
+    if ((tid & 63) == 0) atomicMax(&s_maxdepth, md);
+    __syncthreads();   // every walk is done: lk / lv can be reused
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < ni) {
+        lk[base + e] = (unsigned)dep[e];
+        lv[base + e] = (unsigned)(base + e);
+      }
+    __syncthreads();
+    if (tid == 0) a.result[0] = s_maxdepth;
+  }
+  STAMP(6);
+  // 7. traversal numbering: stable sort of the inner nodes by depth (< 64), then its inverse
+  small_sort(lk, lv, ni, 6);
+  __syncthreads();   // (the sort's last read-back is done)
+  int *order = a.order, *trav_of = a.trav_of;   // global: LDS is about to hold the work lists
+  for (int t = tid; t < ni; t += kSmallNT) {
+    const int c = (int)lv[t];
+    order[t] = c;
+    trav_of[c] = t;
+  }
+  __syncthreads();
+  STAMP(7);
+  // 8. AABB propagation: exactly `sweeps` Jacobi sweeps from all-zero boxes (bvh.fut:47-58).
+  // A node whose children are final (leaves, or inner nodes that were final one sweep earlier)
+  // is final itself; once it has written that value into both ping-pong buffers, recomputing it
+  // would store the same bits again, so it leaves the work list.  Lists hold node | once << 15.
+  float4 *buf[2] = {a.box4, a.box4 + 2 * (size_t)ni};
+  unsigned short *list[2] = {(unsigned short *)small_lds, (unsigned short *)small_lds + ni};
+  __shared__ int s_cnt[3];
+  for (int i = tid; i < 2 * ni; i += kSmallNT) buf[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < ni; i += kSmallNT) list[0][i] = (unsigned short)i;
+  if (tid == 0) {
+    s_cnt[0] = ni;
+    s_cnt[1] = 0;
+    s_cnt[2] = 0;
+  }
+  __syncthreads();
+  int rd = 0;
+  for (int s = 0; s < a.sweeps; ++s, rd ^= 1) {
+    const float4 *__restrict__ prev = buf[rd];
+    float4 *__restrict__ cur = buf[rd ^ 1];
+    const unsigned short *lin = list[rd];
+    unsigned short *lout = list[rd ^ 1];
+    const int count = s_cnt[s % 3];
+    int *cnt_out = &s_cnt[(s + 1) % 3];
+    if (tid == 0) s_cnt[(s + 2) % 3] = 0;   // (last read one sweep ago)
+    for (int i0 = 0; i0 < count; i0 += 2 * kSmallNT) {
+      // two list entries per lane, so that eight box loads are in flight
+      int node[2], kid[2][2];
+      bool act[2], once[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = i0 + u * kSmallNT + tid;
+        act[u] = idx < count;
+        const unsigned ent = act[u] ? lin[idx] : 0u;
+        node[u] = (int)(ent & 0x7fffu);
+        once[u] = (ent >> 15) != 0;
+        kid[u][0] = a.o.left[node[u]];
+        kid[u][1] = a.o.right[node[u]];
+      }
+      float4 A[2][2], B[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool leaf = kid[u][k] <= -2;
+          const float4 *pa = leaf ? a.o.sph + (-2 - kid[u][k]) : prev + 2 * (size_t)kid[u][k];
+          A[u][k] = pa[0];
+          B[u][k] = leaf ? A[u][k] : pa[1];
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float mn[2][3], mx[2][3];
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool leaf = kid[u][k] <= -2;
+          const float4 p = A[u][k], q = B[u][k];
+          mn[k][0] = leaf ? p.x - p.w : p.x;   // sphere_aabb: pos -/+ radius (ray.fut:157-160)
+          mn[k][1] = leaf ? p.y - p.w : p.y;
+          mn[k][2] = leaf ? p.z - p.w : p.z;
+          mx[k][0] = leaf ? p.x + p.w : q.x;
+          mx[k][1] = leaf ? p.y + p.w : q.y;
+          mx[k][2] = leaf ? p.z + p.w : q.z;
+          fin = fin && (leaf || p.w != 0.0f);
+        }
+        if (act[u]) {
+          cur[2 * (size_t)node[u]] = make_float4(f_min(mn[0][0], mn[1][0]), f_min(mn[0][1], mn[1][1]),
+                                                 f_min(mn[0][2], mn[1][2]), fin ? 1.0f : 0.0f);
+          cur[2 * (size_t)node[u] + 1] = make_float4(f_max(mx[0][0], mx[1][0]), f_max(mx[0][1], mx[1][1]),
+                                                     f_max(mx[0][2], mx[1][2]), 0.0f);
+        }
+        // survivors go to the next list (one LDS atomic per wave)
+        const bool keep = act[u] && !(fin && once[u]);
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+        if (km) {
+          int basep = 0;
+          if ((tid & 63) == 0) basep = atomicAdd(cnt_out, __popcll(km));
+          basep = __builtin_amdgcn_readfirstlane(basep);
+          const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+          if (keep) lout[basep + r] = (unsigned short)(node[u] | (fin ? 0x8000 : 0));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  STAMP(8);
+  // 9. canonical boxes and the traversal records, from the newest buffer
+  const float4 *fb = buf[rd];
+  for (int i = tid; i < ni; i += kSmallNT) {
+    const float4 l = fb[2 * (size_t)i], h = fb[2 * (size_t)i + 1];
+    a.o.bmin[3 * (size_t)i + 0] = l.x; a.o.bmin[3 * (size_t)i + 1] = l.y; a.o.bmin[3 * (size_t)i + 2] = l.z;
+    a.o.bmax[3 * (size_t)i + 0] = h.x; a.o.bmax[3 * (size_t)i + 1] = h.y; a.o.bmax[3 * (size_t)i + 2] = h.z;
+  }
+  for (int t = tid; t < ni; t += kSmallNT) {
+    const int c = order[t];
+    const int kid[2] = {a.o.left[c], a.o.right[c]};
+    float4 q[4];
+    int ref[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool leaf = kid[k] <= -2;
+      const size_t at = leaf ? 0 : (size_t)kid[k];
+      const float4 l = fb[2 * at], h = fb[2 * at + 1];
+      ref[k] = leaf ? ~(-2 - kid[k]) : trav_of[at];
+      q[2 * k] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(l.x, l.y, l.z, 0.f);
+      q[2 * k + 1] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(h.x, h.y, h.z, 0.f);
+    }
+    q[0].w = __int_as_float(ref[0]);
+    q[1].w = __int_as_float(ref[1]);
+    a.o.nodes64[4 * (size_t)t + 0] = q[0];
+    a.o.nodes64[4 * (size_t)t + 1] = q[1];
+    a.o.nodes64[4 * (size_t)t + 2] = q[2];
+    a.o.nodes64[4 * (size_t)t + 3] = q[3];
+    const float4 l = fb[2 * (size_t)c], h = fb[2 * (size_t)c + 1];
+    const float4 r0 = make_float4(l.x, l.y, l.z, __int_as_float(ref[0])), r1 = make_float4(h.x, h.y, h.z, __int_as_float(ref[1]));
+    a.o.nodes32[2 * (size_t)t + 0] = r0;
+    a.o.nodes32[2 * (size_t)t + 1] = r1;
+    if (t == 0) {   // the root's box goes straight to the host (tested when a ray starts)
+      float *rr = (float *)(a.result + 4);
+      rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w;
+      rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+    }
+  }
+  __syncthreads();
+  STAMP(9);
+#undef STAMP
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -388,30 +751,92 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
     if (e_ != hipSuccess) return e_;       \
   } while (0)
 
-// Builds everything from n spheres already on the device.  All output arrays are allocated by
-// the caller (sizes in rt_device.hpp: GpuBvhOut).  Scratch is allocated and freed here.
-hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, hipStream_t st, int *height_out) {
-  const int ni = n - 1;
-  const int nb_n = cdiv(n, kBT), nb_ni = cdiv(ni, kBT);
-  const int sort_blocks = cdiv(n, kBT * kSortE);
-  const int red_blocks = nb_n < 1024 ? nb_n : 1024;
-  // one scratch allocation, carved up (256-byte aligned pieces)
+namespace {
+// device scratch of one build, carved from one caller-provided block (256-byte aligned pieces)
+struct ScratchLayout {
+  size_t input, centres, partial, bounds, k0, k1, v0, v1, counts, bufmin, bufmax, depth, trav, flags, box4, total;
+};
+ScratchLayout scratch_layout(int n) {
+  const size_t ni = (size_t)n - 1;
+  const int nb_n = cdiv(n, kBT);
+  const size_t sort_blocks = (size_t)cdiv(n, kBT * kSortE), red_blocks = nb_n < 1024 ? nb_n : 1024;
+  ScratchLayout l{};
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
-  const size_t o_centres = carve(sizeof(float) * 3 * (size_t)n), o_partial = carve(sizeof(float) * 6 * (size_t)red_blocks),
-               o_bounds = carve(sizeof(float) * 8), o_k0 = carve(sizeof(unsigned) * (size_t)n),
-               o_k1 = carve(sizeof(unsigned) * (size_t)n), o_v0 = carve(sizeof(int) * (size_t)n),
-               o_v1 = carve(sizeof(int) * (size_t)n), o_counts = carve(sizeof(unsigned) * 4 * (size_t)sort_blocks + 16),
-               o_bufmin = carve(sizeof(float) * 3 * (size_t)ni), o_bufmax = carve(sizeof(float) * 3 * (size_t)ni),
-               o_depth = carve(sizeof(int) * (size_t)ni), o_trav = carve(sizeof(int) * (size_t)ni), o_flags = carve(sizeof(int) * 4);
-  char *scratch = nullptr;
-  BVH_HIP(hipMalloc((void **)&scratch, off));
-  float *centres = (float *)(scratch + o_centres), *partial = (float *)(scratch + o_partial), *bounds = (float *)(scratch + o_bounds);
-  unsigned *keys[2] = {(unsigned *)(scratch + o_k0), (unsigned *)(scratch + o_k1)}, *counts = (unsigned *)(scratch + o_counts);
-  int *vals[2] = {(int *)(scratch + o_v0), (int *)(scratch + o_v1)};
-  float *bufmin = (float *)(scratch + o_bufmin), *bufmax = (float *)(scratch + o_bufmax);
-  int *depth = (int *)(scratch + o_depth), *trav_of = (int *)(scratch + o_trav), *flags = (int *)(scratch + o_flags);
+  l.input = carve(sizeof(float) * 7 * (size_t)n);
+  l.centres = carve(sizeof(float) * 3 * (size_t)n);
+  if (n <= kSmallMax) {
+    l.box4 = carve(sizeof(float4) * 4 * ni);
+    l.v0 = carve(sizeof(int) * ni);
+    l.trav = carve(sizeof(int) * ni);
+  } else {
+    l.partial = carve(sizeof(float) * 6 * red_blocks);
+    l.bounds = carve(sizeof(float) * 8);
+    l.k0 = carve(sizeof(unsigned) * (size_t)n);
+    l.k1 = carve(sizeof(unsigned) * (size_t)n);
+    l.v0 = carve(sizeof(int) * (size_t)n);
+    l.v1 = carve(sizeof(int) * (size_t)n);
+    l.counts = carve(sizeof(unsigned) * 4 * sort_blocks + 16);
+    l.bufmin = carve(sizeof(float) * 3 * ni);
+    l.bufmax = carve(sizeof(float) * 3 * ni);
+    l.depth = carve(sizeof(int) * ni);
+    l.trav = carve(sizeof(int) * ni);
+    l.flags = carve(sizeof(int) * 64);
+  }
+  l.total = off;
+  return l;
+}
+}  // namespace
 
+size_t gpu_build_scratch_bytes(int n) { return scratch_layout(n).total; }
+// host-pinned block: 64 ints the kernels report through, then staging for a small scene's spheres
+constexpr size_t kPinnedHeader = 64 * sizeof(int);
+size_t gpu_build_pinned_bytes() { return kPinnedHeader + sizeof(float) * 7 * (size_t)kSmallMax + 16; }
+
+// Builds everything from n spheres in host memory.  All output arrays, the scratch block
+// (gpu_build_scratch_bytes(n)) and the host-pinned block (gpu_build_pinned_bytes()) are allocated by
+// the caller (sizes in rt_device.hpp: GpuBvhOut).  Returns after the stream has drained, with the
+// tree height and the root's box.
+hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &o, char *scratch, char *pinned, hipStream_t st,
+                         int *height_out, float root_lo[3], float root_hi[3]) {
+  const int ni = n - 1;
+  const int nb_n = cdiv(n, kBT), nb_ni = cdiv(ni, kBT);
+  const int red_blocks = nb_n < 1024 ? nb_n : 1024;
+  const ScratchLayout l = scratch_layout(n);
+  float *centres = (float *)(scratch + l.centres), *sph7_dev = (float *)(scratch + l.input);
+  int *result = (int *)pinned;
+  const float *root = (const float *)(result + 4);
+
+  if (n <= kSmallMax) {
+    // the whole build in one workgroup / one launch; the kernel pulls the spheres from the pinned block
+    float *stage = (float *)(pinned + kPinnedHeader);
+    memcpy(stage, sph7_host, sizeof(float) * 7 * (size_t)n);
+    SmallArgs a{stage, sph7_dev, n, (int)log2f((float)n) + 2, o, centres, (float4 *)(scratch + l.box4),
+                (int *)(scratch + l.v0), (int *)(scratch + l.trav), result};
+    BVH_HIP(hipFuncSetAttribute((const void *)bvh_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * (int)sizeof(unsigned) * kSmallMax));
+    hipLaunchKernelGGL(bvh_small_kernel, dim3(1), dim3(kSmallNT), 2 * sizeof(unsigned) * (size_t)n, st, a);
+    BVH_HIP(hipGetLastError());
+    BVH_HIP(hipStreamSynchronize(st));
+    *height_out = result[0] + 1;
+    for (int k = 0; k < 3; ++k) {
+      root_lo[k] = root[k];
+      root_hi[k] = root[4 + k];
+    }
+    if (getenv("RT_BVH_STAMPS")) {
+      const unsigned long long *t = (const unsigned long long *)(result + 16);
+      fprintf(stderr, "bvh_small n=%d height=%d: centres %.1f morton %.1f sort %.1f gather %.1f tree %.1f depth %.1f numbering %.1f boxes %.1f records %.1f us\n",
+              n, *height_out, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
+              (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[9] - t[8]) * 0.01);
+    }
+    return hipSuccess;
+  }
+  BVH_HIP(hipMemcpyAsync(sph7_dev, sph7_host, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice, st));
+  float *partial = (float *)(scratch + l.partial), *bounds = (float *)(scratch + l.bounds);
+  unsigned *keys[2] = {(unsigned *)(scratch + l.k0), (unsigned *)(scratch + l.k1)}, *counts = (unsigned *)(scratch + l.counts);
+  int *vals[2] = {(int *)(scratch + l.v0), (int *)(scratch + l.v1)};
+  float *bufmin = (float *)(scratch + l.bufmin), *bufmax = (float *)(scratch + l.bufmax);
+  int *depth = (int *)(scratch + l.depth), *trav_of = (int *)(scratch + l.trav), *flags = (int *)(scratch + l.flags);
   // 1. centres, bounds, Morton keys
   hipLaunchKernelGGL(centres_minmax_kernel, dim3(red_blocks), dim3(kBT), 0, st, sph7_dev, n, centres, partial);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kBT), 0, st, partial, red_blocks, bounds);
@@ -447,10 +872,9 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, hipSt
     BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
     for (int s = 0; s < 8; ++s)
       hipLaunchKernelGGL(depth_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, depth, flags);
-    int changed = 0;
-    BVH_HIP(hipMemcpyAsync(&changed, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    BVH_HIP(hipMemcpyAsync(result + 1, flags, sizeof(int), hipMemcpyDeviceToHost, st));
     BVH_HIP(hipStreamSynchronize(st));
-    if (!changed) break;
+    if (!result[1]) break;
   }
   // 6. traversal numbering: stable sort of the inner nodes by depth (6 bits)
   BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
@@ -465,11 +889,14 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, hipSt
                      ni, o.nodes32, o.nodes64);
   hipLaunchKernelGGL(trav_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, o.L7, n, o.sph, o.col);
   BVH_HIP(hipGetLastError());
-  int maxdepth = 0;
-  BVH_HIP(hipMemcpyAsync(&maxdepth, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  BVH_HIP(hipMemcpyAsync(result, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  BVH_HIP(hipMemcpyAsync(result + 4, o.nodes32, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
   BVH_HIP(hipStreamSynchronize(st));
-  *height_out = maxdepth + 1;   // levels of inner nodes == edges on the longest root -> leaf path
-  (void)hipFree(scratch);
+  *height_out = result[0] + 1;   // levels of inner nodes == edges on the longest root -> leaf path
+  for (int k = 0; k < 3; ++k) {
+    root_lo[k] = root[k];
+    root_hi[k] = root[4 + k];
+  }
   return hipSuccess;
 }
 

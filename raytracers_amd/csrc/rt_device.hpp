@@ -61,7 +61,12 @@ struct GpuBvhOut {
   float4 *nodes64;           // [4*(n-1)]
   float4 *sph, *col;         // [n]
 };
-hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, hipStream_t stream, int *height_out);
+size_t gpu_build_scratch_bytes(int n);   // device scratch one build of n spheres needs
+size_t gpu_build_pinned_bytes();         // host-pinned block: result words + staging for small scenes
+// `sph7_host`: the n spheres in (pageable) host memory; `scratch`, `pinned`: blocks of the sizes
+// above.  Synchronises the stream; returns the tree height and the root's box.
+hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &out, char *scratch, char *pinned, hipStream_t stream,
+                         int *height_out, float root_lo[3], float root_hi[3]);
 
 hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
