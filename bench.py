@@ -8,7 +8,8 @@ A "step" is one frame of EACH scene of the headline metric (BASELINE.json: "Mray
 (primary+secondary) on rgbbox & irreg 1000x1000"): render rgbbox 1000x1000, then irreg
 1000x1000, scene data (BVH, spheres, camera) already resident in HBM.  With N > 1 every
 frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total work fixed) and
-the framebuffer is gathered to rank 0 over RCCL inside the timed region.
+the framebuffers of a step are gathered to rank 0 over RCCL inside the timed region (ONE
+gather per step: a rank's rows of both frames travel in one send buffer).
 
 Steps are independent frames, so up to --frames-in-flight of them (default 8) are enqueued
 on separate HIP streams, each with its own context and framebuffers: a 1000x1000 frame ends
@@ -154,7 +155,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
+    from raytracers_amd.dist import HipPartRenderer, ShardedStep
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
@@ -168,12 +169,14 @@ def main():
     # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
 
+    class Lane:
+        """the renderers of one frame in flight + the step (render all, one gather, assemble)"""
+        def __init__(self, o):
+            self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in frames]
+            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, frames)], device)
+
     def make_lane(o):
-        lane = []
-        for scene, h, w in frames:
-            pr = HipPartRenderer(scene, h, w, device, variant=args.variant, options=o)
-            lane.append((scene, h, w, pr, ShardedRenderer(pr, h, w, device)))
-        return lane
+        return Lane(o)
 
     lanes = []
     for st in streams:
@@ -181,11 +184,11 @@ def main():
             lanes.append(make_lane(opts_pipe))
     serial_lane = make_lane(opts) if (S > 1 and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
-    renderers = lanes[0]
+    renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, lanes[0].prs)]
 
     # work per frame: instrumented launch (rank 0 is enough), checked against the oracle table
     work = {}
-    for scene, h, w, pr, _ in renderers:
+    for scene, h, w, pr in renderers:
         st = pr.prepared.stats()
         got = (st["rays"], st["box_tests"], st["leaf_tests"])
         want = FRAME_WORK.get((scene, h, w))
@@ -195,13 +198,11 @@ def main():
 
     def step(k, events=None, nlanes=S):
         if nlanes == 0:       # the one-frame-at-a-time lane (library defaults, default stream)
-            for i, (_, _, _, _, sr) in enumerate(serial_lane):
-                sr.render(events[i] if events is not None else None)
+            serial_lane.step.render(events)
             return
         li = k % nlanes
         with torch.cuda.stream(streams[li]):
-            for i, (_, _, _, _, sr) in enumerate(lanes[li]):
-                sr.render(events[i] if events is not None else None)
+            lanes[li].step.render(events)
 
     def fence():
         torch.cuda.synchronize()
@@ -239,7 +240,7 @@ def main():
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
         value = rays_step * args.steps / elapsed / 1e6
         per_scene = {}
-        for i, (scene, h, w, _, _) in enumerate(renderers):
+        for i, (scene, h, w, _) in enumerate(renderers):
             r, b, s = work[(scene, h, w)]
             ba = bytes_alg(b, s, h, w) / world        # this rank's share of the frame (cyclic tiles)
             per_scene[f"{scene}_{w}x{h}"] = {
@@ -259,7 +260,7 @@ def main():
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
                        "options": opts_pipe, "frames_in_flight": S,
-                       "partition": f"cyclic 8-row tiles over {world} GPU(s), RCCL gather to rank 0"
+                       "partition": f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per step"
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
             "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
                          + f" on {dscene} {dw}x{dh}",
@@ -305,7 +306,14 @@ def main():
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL's banner sits in the C library's stdout buffer (a pipe is fully buffered) and would
+    # otherwise surface AFTER the JSON line at exit: push it out while fd 1 still is stderr
     sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
     os.dup2(saved_stdout, 1)
     if result_line is not None:
         print(result_line, flush=True)

@@ -101,6 +101,10 @@ int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, 
  * ranks' padded send buffers delivers on rank 0), one kernel. */
 int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t pad_rows,
                    const int32_t *stacked_dev, int32_t *image_dev);
+/* General form: part p's packed rows start at stacked_dev + p * part_stride (int32 elements), so one
+ * gathered buffer may carry the parts of several frames (one gather per step, see dist.py). */
+int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts,
+                           int64_t part_stride, const int32_t *stacked_dev, int32_t *image_dev);
 
 /* Work counters of one frame, computed on the device by an instrumented launch of the
  * same traversal: rays (objs_hit calls), box tests, sphere tests. */

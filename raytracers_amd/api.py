@@ -257,7 +257,12 @@ def place_part(ctx, h, w, part, nparts, part_ptr, image_ptr, rows_per_tile=ROWS_
                                  C.c_void_p(part_ptr), C.c_void_p(image_ptr)))
 
 
-def place_parts(ctx, h, w, nparts, pad_rows, stacked_ptr, image_ptr, rows_per_tile=ROWS_PER_TILE):
-    """All gathered parts (nparts x pad_rows x w) -> the h x w image, one kernel."""
-    ctx._check(lib.rt_place_parts(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(pad_rows),
-                                  C.c_void_p(stacked_ptr), C.c_void_p(image_ptr)))
+def place_parts(ctx, h, w, nparts, pad_rows, stacked_ptr, image_ptr, rows_per_tile=ROWS_PER_TILE, part_stride=None):
+    """All gathered parts -> the h x w image, one kernel.  Part p's packed rows start at
+    stacked_ptr + 4 * p * part_stride (default: pad_rows * w, i.e. nparts x pad_rows x w)."""
+    if part_stride is None:
+        ctx._check(lib.rt_place_parts(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(pad_rows),
+                                      C.c_void_p(stacked_ptr), C.c_void_p(image_ptr)))
+    else:
+        ctx._check(lib.rt_place_parts_strided(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(part_stride),
+                                              C.c_void_p(stacked_ptr), C.c_void_p(image_ptr)))

@@ -625,17 +625,23 @@ extern "C" int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows
   return 0;
 }
 
-extern "C" int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t pad_rows,
-                              const int32_t *stacked_dev, int32_t *image_dev) {
+extern "C" int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts,
+                                      int64_t part_stride, const int32_t *stacked_dev, int32_t *image_dev) {
   if (!ctx || !stacked_dev || !image_dev) return fail(ctx, "null argument");
   if (rows_per_tile <= 0 || nparts <= 0 || h <= 0 || w <= 0) return fail(ctx, "bad row-tile partition");
   int64_t need = 0;
   for (int p = 0; p < nparts; ++p) need = std::max<int64_t>(need, rt::part_rows(h, rows_per_tile, p, nparts));
-  if (pad_rows < need) return fail(ctx, "pad_rows smaller than the largest part");
+  if (part_stride < need * w) return fail(ctx, "part stride smaller than the largest part");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, rtk::launch_place_all(stacked_dev, image_dev, static_cast<int>(w), static_cast<int>(h), rows_per_tile, nparts,
-                                    static_cast<int>(pad_rows), ctx->stream));
+                                    static_cast<size_t>(part_stride), ctx->stream));
   return 0;
+}
+
+extern "C" int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t pad_rows,
+                              const int32_t *stacked_dev, int32_t *image_dev) {
+  if (pad_rows < 0 || w <= 0) return fail(ctx, "bad row-tile partition");
+  return rt_place_parts_strided(ctx, h, w, rows_per_tile, nparts, pad_rows * w, stacked_dev, image_dev);
 }
 
 extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,

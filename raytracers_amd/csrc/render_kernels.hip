@@ -658,16 +658,17 @@ __global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, in
   }
 }
 
-// All parts at once: `stacked` = nparts x pad_rows x w (what a gather to rank 0 delivers).
+// All parts at once: part p's packed rows start at stacked + p * part_stride (what a gather of the
+// ranks' send buffers to rank 0 delivers; one send buffer may carry several frames).
 __global__ void place_all_kernel(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                                 int pad_rows) {
+                                 size_t part_stride) {
   const size_t total = (size_t)h * w;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / w), col = (int)(i - (size_t)row * w);
     const int t = row / rows_per_tile;
     const int part = t % nparts, k = t / nparts;
     const int lrow = k * rows_per_tile + (row - t * rows_per_tile);
-    image[i] = stacked[((size_t)part * pad_rows + lrow) * w + col];
+    image[i] = stacked[(size_t)part * part_stride + (size_t)lrow * w + col];
   }
 }
 
@@ -755,12 +756,12 @@ hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int row
 }
 
 hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                            int pad_rows, hipStream_t stream) {
+                            size_t part_stride, hipStream_t stream) {
   const size_t total = (size_t)h * w;
   if (total == 0) return hipSuccess;
   const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(place_all_kernel, dim3(grid), dim3(256), 0, stream, stacked, image, w, h, rows_per_tile, nparts,
-                     pad_rows);
+                     part_stride);
   return hipGetLastError();
 }
 

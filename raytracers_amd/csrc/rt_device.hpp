@@ -73,6 +73,6 @@ hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int row
                              int nparts, hipStream_t stream);
 
 hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                            int pad_rows, hipStream_t stream);
+                            size_t part_stride, hipStream_t stream);
 
 }  // namespace rtk

@@ -57,29 +57,37 @@ class HipPartRenderer:
     def place(self, part, nparts, part_tensor, image):
         api.place_part(self.ctx, self.h, self.w, part, nparts, part_tensor.data_ptr(), image.data_ptr())
 
-    def place_all(self, nparts, pad_rows, stacked, image):
-        api.place_parts(self.ctx, self.h, self.w, nparts, pad_rows, stacked.data_ptr(), image.data_ptr())
+    def place_all(self, nparts, pad_rows, stacked, image, part_stride=None):
+        """stacked: a tensor whose element 0 is part 0's first pixel; part p starts part_stride
+        int32 elements further (default pad_rows * w)."""
+        api.place_parts(self.ctx, self.h, self.w, nparts, pad_rows, stacked.data_ptr(), image.data_ptr(),
+                        part_stride=part_stride)
 
 
-class ShardedRenderer:
-    """render(h, w) across the ranks of a torch.distributed group: each rank renders its
-    cyclic row tiles, rank `dst` gathers and assembles the [h][w]i32 image.
+class ShardedStep:
+    """One step = one frame of each of several scenes, across the ranks of a torch.distributed
+    group: every rank renders its cyclic row tiles of every frame into ONE send buffer, ONE
+    gather moves them to rank `dst`, which assembles the [h][w]i32 images (one kernel each).
 
-    part_renderer(part, nparts, out) must fill out[:part_rows] (out: [pad_rows, w] int32 on
-    `device`) and may be asynchronous on the device's current stream."""
+    frames: list of (part_renderer, h, w); part_renderer(part, nparts, out) must fill
+    out[:part_rows] (out: [pad_rows, w] int32 on `device`) and may be asynchronous on the
+    device's current stream."""
 
-    def __init__(self, part_renderer, h, w, device, group=None, dst=0):
-        self.render_part = part_renderer
-        self.h, self.w, self.group, self.dst = h, w, group, dst
+    def __init__(self, frames, device, group=None, dst=0):
+        self.frames = list(frames)
+        self.group, self.dst = group, dst
         self.device = torch.device(device)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.pad_rows = max_part_rows(h, self.world)
+        self.pad_rows = [max_part_rows(h, self.world) for _, h, _ in self.frames]
+        sizes = [pr * w for pr, (_, _, w) in zip(self.pad_rows, self.frames)]
+        self.offs = [int(o) for o in np.concatenate([[0], np.cumsum(sizes)])]   # int32 elements
+        self.total = self.offs[-1]
         self.recv_all = None
         self.recv = None
-        self.image = None
+        self.images = None
         if self.rank == dst:
-            self.image = torch.empty((h, w), dtype=torch.int32, device=self.device)
+            self.images = [torch.empty((h, w), dtype=torch.int32, device=self.device) for _, h, w in self.frames]
         # A CPU-only backend (gloo) cannot move device memory: stage the gather through host
         # buffers then.  Only used to exercise the multi-rank control flow on a one-GPU box
         # (several ranks sharing cuda:0); the product path is backend "nccl" = RCCL over xGMI.
@@ -89,27 +97,31 @@ class ShardedRenderer:
         # exercise the RCCL path on a one-GPU box)
         self.direct = self.world == 1 and not (dist.is_initialized() and os.environ.get("RT_FORCE_GATHER"))
         if self.direct:
-            self.send = self.image            # one part == the whole image: nothing to gather or assemble
+            self.outs = self.images            # one part == the whole image: nothing to gather or assemble
         else:
-            self.send = torch.zeros((self.pad_rows, w), dtype=torch.int32, device=self.device)
+            self.send = torch.zeros(self.total, dtype=torch.int32, device=self.device)
+            self.outs = [self.send[self.offs[i]:self.offs[i + 1]].view(self.pad_rows[i], w)
+                         for i, (_, _, w) in enumerate(self.frames)]
             if self.rank == dst:
                 # one contiguous buffer; gather_list entries are views of it so that a single
-                # kernel can scatter all parts into the image
-                self.recv_all = torch.empty((self.world, self.pad_rows, w), dtype=torch.int32, device=self.device)
+                # kernel per frame can scatter all parts into the image
+                self.recv_all = torch.empty((self.world, self.total), dtype=torch.int32, device=self.device)
                 self.recv = [self.recv_all[p] for p in range(self.world)]
 
     def render(self, events=None):
-        """One frame.  Returns the full image tensor on rank dst, None elsewhere.  `events`:
-        an optional (start, end) pair of torch.cuda.Event recorded around this rank's kernel."""
-        if events is not None:
-            events[0].record()
-        self.render_part(self.rank, self.world, self.send)
-        if events is not None:
-            events[1].record()
+        """One step.  Returns the list of full image tensors on rank dst, None elsewhere.
+        `events`: optional list (one per frame) of (start, end) torch.cuda.Event pairs recorded
+        around this rank's kernel of that frame."""
+        for i, (render_part, _, _) in enumerate(self.frames):
+            if events is not None and events[i] is not None:
+                events[i][0].record()
+            render_part(self.rank, self.world, self.outs[i])
+            if events is not None and events[i] is not None:
+                events[i][1].record()
         if self.direct:
-            return self.image
+            return self.images
         if self.host_staged:
-            send_h = self.send.cpu()      # synchronises with the render on the current stream
+            send_h = self.send.cpu()      # synchronises with the renders on the current stream
             recv_h = [torch.empty_like(send_h) for _ in range(self.world)] if self.rank == self.dst else None
             dist.gather(send_h, recv_h, dst=self.dst, group=self.group)
             if self.rank != self.dst:
@@ -119,15 +131,36 @@ class ShardedRenderer:
             dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
             if self.rank != self.dst:
                 return None
-        self._assemble()
-        return self.image
+        for i in range(len(self.frames)):
+            self._assemble(i)
+        return self.images
 
-    def _assemble(self):
-        if self.image.is_cuda and hasattr(self.render_part, "place_all"):
-            self.render_part.place_all(self.world, self.pad_rows, self.recv_all, self.image)
+    def _assemble(self, i):
+        render_part, h, w = self.frames[i]
+        image, stacked = self.images[i], self.recv_all[:, self.offs[i]:self.offs[i + 1]]
+        if image.is_cuda and hasattr(render_part, "place_all"):
+            render_part.place_all(self.world, self.pad_rows[i], stacked, image, part_stride=self.total)
             return
         for p in range(self.world):
-            n = api.part_rows(self.h, p, self.world)
+            n = api.part_rows(h, p, self.world)
             if n:
-                idx = torch.as_tensor(tile_rows(self.h, p, self.world), device=self.image.device)
-                self.image[idx] = self.recv_all[p, :n]
+                idx = torch.as_tensor(tile_rows(h, p, self.world), device=image.device)
+                image[idx] = stacked[p].view(self.pad_rows[i], w)[:n]
+
+
+class ShardedRenderer(ShardedStep):
+    """render(h, w) of ONE frame across the ranks (a ShardedStep with a single frame)."""
+
+    def __init__(self, part_renderer, h, w, device, group=None, dst=0):
+        super().__init__([(part_renderer, h, w)], device, group=group, dst=dst)
+        self.render_part, self.h, self.w = part_renderer, h, w
+
+    @property
+    def image(self):
+        return self.images[0] if self.images is not None else None
+
+    def render(self, events=None):
+        """One frame.  Returns the full image tensor on rank dst, None elsewhere.  `events`:
+        an optional (start, end) pair of torch.cuda.Event recorded around this rank's kernel."""
+        out = super().render([events] if events is not None else None)
+        return out[0] if out is not None else None

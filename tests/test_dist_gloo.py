@@ -68,6 +68,43 @@ def test_two_rank_gather_equals_single_render(scene, h, w):
     assert (img == full).all()
 
 
+def _step_worker(rank, world, port, frames, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracers_amd.dist import ShardedStep
+        st = ShardedStep([(OraclePartRenderer(s, h, w), h, w) for s, h, w in frames], device="cpu")
+        imgs = st.render()
+        imgs = st.render()   # buffers are reused across steps
+        if rank == 0:
+            q.put([i.numpy().copy() for i in imgs])
+        else:
+            assert imgs is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_gather_per_step_of_several_frames(world):
+    """ShardedStep: the rows of two frames of different sizes travel in ONE gather."""
+    frames = [("rgbbox", 27, 24), ("irreg", 41, 32)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    imgs = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for (scene, h, w), img in zip(frames, imgs):
+        full, _ = O.OracleScene(scene).render(h, w)
+        assert (img == full).all()
+
+
 def test_single_rank_path_without_process_group():
     from raytracers_amd.dist import ShardedRenderer
     h, w = 20, 16

@@ -434,12 +434,17 @@ def test_odd_rows_per_tile_on_the_non_pooled_families(R, ctx, variant):
 
 
 # ---------------------------------------------------------------- the bench contract ------
-def test_bench_line_contract(tmp_path):
-    """bench.py prints exactly ONE line on stdout, a JSON object with the keys the driver reads."""
+@pytest.mark.parametrize("force_gather", [0, 1])
+def test_bench_line_contract(tmp_path, force_gather):
+    """bench.py prints exactly ONE line on stdout, a JSON object with the keys the driver reads
+    (force_gather: the RCCL gather + assembly path on one rank; RCCL's banner must not reach stdout)."""
     import json
     import sys
+    env = dict(os.environ)
+    if force_gather:
+        env["RT_FORCE_GATHER"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[:500]
@@ -464,15 +469,20 @@ def _rank_worker(rank, world, port, scene, h, w, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from raytracers_amd.dist import HipPartRenderer, ShardedRenderer
+        from raytracers_amd.dist import HipPartRenderer, ShardedRenderer, ShardedStep
         torch.cuda.set_device(0)
         pr = HipPartRenderer(scene, h, w, "cuda:0")
         sr = ShardedRenderer(pr, h, w, device="cuda:0")
         for _ in range(3):
             img = sr.render()
+        # a step of two frames of different sizes: one gather, strided placement
+        pr2 = HipPartRenderer("rgbbox", 77, 96, "cuda:0")
+        st = ShardedStep([(pr, h, w), (pr2, 77, 96)], device="cuda:0")
+        for _ in range(2):
+            imgs = st.render()
         torch.cuda.synchronize()
         if rank == 0:
-            q.put(img.cpu().numpy().copy())
+            q.put((img.cpu().numpy().copy(), [i.cpu().numpy().copy() for i in imgs]))
     finally:
         dist.destroy_process_group()
 
@@ -490,9 +500,12 @@ def test_multi_rank_render_sharing_one_gpu(world):
     procs = [ctxm.Process(target=_rank_worker, args=(r, world, port, scene, h, w, q)) for r in range(world)]
     for p in procs:
         p.start()
-    img = q.get(timeout=300)
+    img, step_imgs = q.get(timeout=300)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
     want, _ = _oracle(scene).render(h, w)
     assert int((img != want).sum()) == 0
+    assert int((step_imgs[0] != want).sum()) == 0
+    want2, _ = _oracle("rgbbox").render(77, 96)
+    assert int((step_imgs[1] != want2).sum()) == 0
