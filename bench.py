@@ -11,7 +11,7 @@ frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total wor
 the framebuffers of a step are gathered to rank 0 over RCCL inside the timed region (ONE
 gather per step: a rank's rows of both frames travel in one send buffer).
 
-Steps are independent frames, so up to --frames-in-flight of them (default 8) are enqueued
+Steps are independent frames, so up to --frames-in-flight of them (default 32) are enqueued
 on separate HIP streams, each with its own context and framebuffers: a 1000x1000 frame ends
 with a long tail in which a handful of 50-bounce pixels keep a few waves busy (the frame's
 latency floor), and the next frames' bulk work fills the otherwise idle machine.  All K
@@ -43,8 +43,11 @@ sys.path.insert(0, ROOT)
 
 # The frames in flight live on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES
 # hardware queues (default 4, and torch / RCCL take some), and streams that share a queue
-# serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# largely serialise.  Measured on one MI355X (tools/rank_share_probe.py): 8 queues
+# 0.69 ms/step, 12-16 queues 0.54-0.60 and bimodal, 20 queues with 32 lanes 0.53 and steady;
+# with MORE than ~20 queues actually busy (24+ queues and 24+ lanes) the hardware scheduler
+# oversubscribes and a step takes 0.7-1.2 ms.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -124,7 +127,9 @@ def main():
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=8, help="independent steps enqueued concurrently (streams)")
+    ap.add_argument("--frames-in-flight", type=int, default=32, help="independent steps enqueued concurrently (streams)")
+    ap.add_argument("--event-every", type=int, default=1,
+                    help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
     ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -159,13 +164,18 @@ def main():
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
+    # Frames in flight and launch size, from tools/rank_share_probe.py (one rank's share of a step at
+    # world sizes 1..8, measured on one MI355X with 20 hardware queues): 32 lanes are steady at
+    # every world size (8 or 16 lanes are bimodal, e.g. 0.50 / 0.56 ms per step), and as a rank's
+    # share of a frame shrinks it takes that many frames in flight to cover a frame's latency
+    # floor (its longest bounce chain): 505 / 252 / 142 / 87 us per step at 1 / 2 / 4 / 8 ranks.
     S = max(1, args.frames_in_flight)
-    # With several frames in flight a launch need not fill the machine by itself: a quarter of
-    # the persistent workgroups per launch gives longer-lived, better-filled waves (its longer
-    # tail is hidden by the other frames).  One frame at a time keeps the library default.
+    # With many frames in flight a launch need not fill the machine by itself: an eighth of the
+    # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is
+    # hidden by the other frames.  One frame at a time keeps the library default.
     opts_pipe = dict(opts)
     if S >= 4 and args.variant in (0, 3):
-        opts_pipe.setdefault("grid_div", 4)
+        opts_pipe.setdefault("grid_div", 8)
     # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
 
@@ -211,8 +221,9 @@ def main():
             torch.cuda.synchronize()
 
     def timed(nsteps, nlanes):
+        every = max(1, args.event_every)
         ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
-              for _ in range(nsteps)]
+              if k % every == 0 else None for k in range(nsteps)]
         fence()
         t0 = time.perf_counter()
         for k in range(nsteps):
@@ -224,10 +235,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         # per-launch durations on this rank: events recorded on the stream each kernel is launched on
-        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nsteps)])) for i in range(len(frames))]
+        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nsteps) if ev[k] is not None]))
+               for i in range(len(frames))]
         return dt, kms
 
-    for k in range(max(args.warmup, S)):
+    # Lane set-up: every lane renders its frames twice, which fills the per-view caches (u/v tables;
+    # the adaptive tile order is computed once from the first frame's cost record).  Then the W
+    # untimed warm-up steps, then exactly K timed steps.
+    for k in range(2 * S):
+        step(k)
+    for k in range(args.warmup):
         step(k)
     elapsed, kern_ms = timed(args.steps, S)
     serial = None
