@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=${1:-round}
 OUT=$PWD/gpurun_out/$TAG
-export GPU_MAX_HW_QUEUES=16
+# (bench.py sets GPU_MAX_HW_QUEUES itself)
 mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> $OUT/pytest_gpu.log
