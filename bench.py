@@ -299,10 +299,23 @@ def main():
         # figure comes from the committed PMC passes (profiles/traffic.json, tools/gpu_pmc.sh)
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tr = json.load(f).get(f"pooled_kernel {dscene} {dw}x{dh}")
+                trj = json.load(f)
+            tr = trj.get(f"pooled_kernel {dscene} {dw}x{dh}")
             if tr and args.variant in (0, 3) and world == 1:
                 out["roofline"]["traffic"] = tr["hbm_bytes"]
-        except (OSError, ValueError):
+            # what actually bounds this kernel: VALU issue.  wave-instructions of all launches of a
+            # step (PMC SQ_INSTS_VALU at the bench's launch size) / step time, against one VALU
+            # wave64 instruction per 4 clocks per SIMD at the 2.4 GHz peak clock
+            key = "valu_insts_bench_launch" if opts_pipe.get("grid_div", 1) == 8 else "valu_insts"
+            vi = [trj.get(f"pooled_kernel {s} {w}x{h}", {}).get(key) for s, h, w in frames]
+            if all(vi) and args.variant in (0, 3) and world == 1:
+                peak = 256 * 4 * 2.4e9 / 4
+                ach = sum(vi) * args.steps / elapsed
+                out["roofline"]["valu"] = {"bound": "valu issue", "insts_per_step": sum(vi), "achieved": ach / 1e9,
+                                           "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
+                                           "note": "SQ_INSTS_VALU per launch from the committed PMC pass (profiles/"
+                                                   "traffic.json) x launches per step / measured step time"}
+        except (OSError, ValueError, KeyError):
             pass
         if serial is not None:
             sdt, skms = serial

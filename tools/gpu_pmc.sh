@@ -13,6 +13,8 @@ PASSES=(
 "GRBM_GUI_ACTIVE FETCH_SIZE"
 "GRBM_COUNT WRITE_SIZE"
 )
+# PMC_FIRST_ONLY=1: only the instruction-count pass
+if [ -n "$PMC_FIRST_ONLY" ]; then PASSES=("${PASSES[0]}"); fi
 cd /tmp
 for s in $SCENES; do for v in $VARS; do
   i=0

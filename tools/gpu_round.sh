@@ -22,6 +22,8 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-serial-extra > $OUT/rocprof_bench.log 2>&1
 cd $OLDPWD
 bash tools/gpu_pmc.sh $TAG/pmc "3" "rgbbox irreg" > $OUT/pmc.log 2>&1
+PMC_FIRST_ONLY=1 EXTRA_OPTS="-o grid_div=8" bash tools/gpu_pmc.sh $TAG/pmc_gd8 "3" "rgbbox irreg" > $OUT/pmc_gd8.log 2>&1
+python tools/make_traffic_json.py $OUT/pmc $OUT/pmc_gd8 > $OUT/traffic.json 2> $OUT/traffic.err
 python tools/rocpd_summary.py $OUT/prof_bench > $OUT/summary_bench_kernel_trace.txt 2>&1
 python tools/rocpd_summary.py $OUT/pmc/*_p[0-9] > $OUT/summary_pmc.txt 2>&1
 echo round done
