@@ -332,6 +332,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   unsigned *const wleaf = wbox + p.capb;
   const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
+  const __amdgpu_buffer_rsrc_t rs_col = make_rsrc(p.col, (unsigned)p.n_sph * 16u);
 
   for (int i = threadIdx.x; i < 4 * p.lds_nodes; i += THREADS) smem[i] = p.nodes64[i];
   for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) smem[sph_base + i] = p.sph[i];
@@ -384,10 +385,20 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           const float best = __uint_as_float((unsigned)(key >> 32));
           const bool hit = key != kKeyInit;
           const int bestj = (int)((unsigned)key >> 1);
-          float4 s = make_float4(0.f, 0.f, 0.f, 1.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (hit) {
-            s = p.sph[bestj];
-            c = p.col[bestj];
+          // winner's sphere and colour: both loads are issued before either is used (two
+          // dependent global latencies in a row were ~10 % of a lone wave's bounce); the sphere
+          // comes from the LDS copy when it is staged
+          const int wj = hit ? bestj : 0;
+          float4 c = buf_load16(rs_col, wj * 16), s;
+          if (ALL_LDS) {
+            s = smem[sph_base + wj];
+          } else {
+            s = smem[sph_base + (wj < p.lds_sph ? wj : 0)];
+            if (wj >= p.lds_sph) s = buf_load16(rs_sph, wj * 16);
+          }
+          if (!hit) {
+            s = make_float4(0.f, 0.f, 0.f, 1.f);
+            c = make_float4(0.f, 0.f, 0.f, 0.f);
           }
           // the (0.0, t+1) re-intersection returns t = best unless the fold's root was
           // displaced (near_root) or best+1 rounds to best: only then redo it literally
