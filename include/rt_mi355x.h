@@ -66,7 +66,11 @@ int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7
 int64_t rt_scene_num_spheres(const rt_scene *scene);
 int rt_scene_free(rt_context *ctx, rt_scene *scene);
 
-/* ---- prepare_scene (ray.fut:241-244): BVH build + camera, uploaded to the device - */
+/* ---- prepare_scene (ray.fut:241-244): BVH build + camera, on the device ------------------
+ * Values are tied to their context, as in the Futhark C API: the first prepare_scene of a scene
+ * uploads its spheres to the context's device (the scene is device resident from then on), the
+ * prepared scene's arrays live in the context's memory pool -- free it with the SAME context,
+ * before that context is destroyed. */
 int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, int64_t w, const rt_scene *scene);
 int rt_prepared_free(rt_context *ctx, rt_prepared *ps);
 int64_t rt_prepared_num_spheres(const rt_prepared *ps);

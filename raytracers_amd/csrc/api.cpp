@@ -62,11 +62,20 @@ struct rt_context {
     size_t bytes;
   };
   std::vector<Block> pool;
-  char *pinned = nullptr;  // host-pinned block the build kernels report through / read small scenes from
+  // One arena allocated with the context serves the blocks of small scenes (64 KiB granules, first
+  // fit): the first prepare_scene then pays no hipMalloc either.
+  char *arena = nullptr;
+  std::vector<unsigned char> arena_used;   // one flag per granule
+  char *pinned = nullptr;  // host-pinned block the build kernels report through
+  char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
 };
 
 struct rt_scene {
   rt::SceneDesc desc;
+  // Device copy of the spheres, made by the first prepare_scene on a device (the reference's scene
+  // is a device-resident value too: futhark_entry_rgbbox/irreg build it there).
+  mutable float *dev = nullptr;
+  mutable int dev_id = -1;
 };
 
 // Tile-order state of one (image size, partition, depth, camera) view of a prepared scene.
@@ -113,8 +122,27 @@ int hip_fail(rt_context *ctx, hipError_t e, const char *what) {
 
 // ---- device-block pool -------------------------------------------------------------------------
 constexpr size_t kPoolMaxBlocks = 8, kPoolMaxBlockBytes = size_t(256) << 20;
+constexpr size_t kGranule = size_t(64) << 10, kArenaGranules = 256;   // 16 MiB arena per context
+constexpr size_t kStageBytes = size_t(1) << 20;
+
 hipError_t pool_alloc(rt_context *ctx, char **out, size_t *bytes_io) {
-  const size_t want = (*bytes_io + 0xffff) & ~size_t(0xffff);   // 64 KiB granules make repeats hit
+  const size_t want = (*bytes_io + kGranule - 1) & ~(kGranule - 1);   // granules make repeats hit
+  // 1. the arena (small scenes)
+  const size_t g = want / kGranule;
+  if (ctx->arena && g <= kArenaGranules / 2) {
+    size_t run = 0;
+    for (size_t i = 0; i < kArenaGranules; ++i) {
+      run = ctx->arena_used[i] ? 0 : run + 1;
+      if (run == g) {
+        const size_t first = i + 1 - g;
+        std::fill(ctx->arena_used.begin() + static_cast<long>(first), ctx->arena_used.begin() + static_cast<long>(i + 1), 1);
+        *out = ctx->arena + first * kGranule;
+        *bytes_io = want;
+        return hipSuccess;
+      }
+    }
+  }
+  // 2. a cached block of a fitting size
   size_t best = ctx->pool.size();
   for (size_t i = 0; i < ctx->pool.size(); ++i)
     if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want &&
@@ -132,6 +160,11 @@ hipError_t pool_alloc(rt_context *ctx, char **out, size_t *bytes_io) {
 // (the caller has drained every stream that used the block)
 void pool_free(rt_context *ctx, char *p, size_t bytes) {
   if (!p) return;
+  if (ctx && ctx->arena && p >= ctx->arena && p < ctx->arena + kArenaGranules * kGranule) {
+    const size_t first = static_cast<size_t>(p - ctx->arena) / kGranule, g = bytes / kGranule;
+    std::fill(ctx->arena_used.begin() + static_cast<long>(first), ctx->arena_used.begin() + static_cast<long>(first + g), 0);
+    return;
+  }
   if (!ctx || bytes > kPoolMaxBlockBytes) {
     (void)hipFree(p);
     return;
@@ -351,6 +384,11 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (hipMemset(ctx->queue_dev, 0, 256) != hipSuccess) return 7;
   if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return 7;
   if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return 7;
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->arena), kArenaGranules * kGranule) != hipSuccess) return 7;
+  ctx->arena_used.assign(kArenaGranules, 0);
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault) != hipSuccess)
+    return 7;
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), kStageBytes, hipHostMallocDefault) != hipSuccess) return 7;
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
   *out = ctx.release();
   return 0;
@@ -367,7 +405,9 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
+  if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -478,6 +518,10 @@ extern "C" int64_t rt_scene_num_spheres(const rt_scene *scene) {
   return scene ? static_cast<int64_t>(scene->desc.spheres.size()) : 0;
 }
 extern "C" int rt_scene_free(rt_context *, rt_scene *scene) {
+  if (scene && scene->dev) {
+    (void)hipSetDevice(scene->dev_id);
+    (void)hipFree(scene->dev);
+  }
   delete scene;
   return 0;
 }
@@ -516,15 +560,35 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   };
   if (ctx->gpu_build) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
+    if (scene->dev == nullptr || scene->dev_id != ctx->device) {
+      if (scene->dev) {
+        (void)hipSetDevice(scene->dev_id);
+        (void)hipFree(scene->dev);
+        scene->dev = nullptr;
+        (void)hipSetDevice(ctx->device);
+      }
+      const size_t sbytes = n * sizeof(rt::Sphere);
+      e = hipMalloc(reinterpret_cast<void **>(&scene->dev), sbytes + 16);
+      if (e == hipSuccess) {
+        if (sbytes + 16 <= kStageBytes) {
+          // small scene: through the pinned staging block and a copy kernel (a pageable hipMemcpy of
+          // a few hundred KB costs milliseconds)
+          std::memcpy(ctx->stage, scene->desc.spheres.data(), sbytes);
+          e = rtk::gpu_copy_from_pinned(scene->dev, ctx->stage, sbytes, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        } else {
+          e = hipMemcpy(scene->dev, scene->desc.spheres.data(), sbytes, hipMemcpyHostToDevice);
+        }
+      }
+      scene->dev_id = ctx->device;
+    }
     size_t tmp_bytes = rtk::gpu_build_scratch_bytes(static_cast<int>(n));
     char *tmp = nullptr;
-    e = pool_alloc(ctx, &tmp, &tmp_bytes);
-    if (e == hipSuccess && !ctx->pinned)
-      e = hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault);
+    if (e == hipSuccess) e = pool_alloc(ctx, &tmp, &tmp_bytes);
     if (e == hipSuccess) {
       rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
-      e = rtk::gpu_build_bvh(reinterpret_cast<const float *>(scene->desc.spheres.data()), static_cast<int>(n), o, tmp,
-                             ctx->pinned, ctx->stream, &ps->height, ps->root_lo, ps->root_hi);
+      e = rtk::gpu_build_bvh(scene->dev, static_cast<int>(n), o, tmp, ctx->pinned, ctx->stream, &ps->height, ps->root_lo,
+                             ps->root_hi);
     }
     if (tmp) {
       (void)hipStreamSynchronize(ctx->stream);

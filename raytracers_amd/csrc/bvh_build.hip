@@ -308,29 +308,38 @@ __device__ __forceinline__ void aabb_sweep_node(int i, const float *L7, const in
     cmax[3 * (size_t)i + a] = f_max(mx[0][a], mx[1][a]);
   }
 }
+// fin[i] = the sweep in which node i first computed its FINAL box (children final one sweep
+// earlier, or leaves); INT_MAX until then.  Once that value sits in both ping-pong buffers
+// (sweeps fin and fin + 1) recomputing it would store the same bits again: the thread returns.
 __global__ __launch_bounds__(kBT) void aabb_sweep_kernel(const float *L7, const int *left, const int *right, int ni,
-                                                         const float *pmin, const float *pmax, float *cmin, float *cmax) {
+                                                         const float *pmin, const float *pmax, float *cmin, float *cmax,
+                                                         int *fin, int sweep) {
   const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i < ni) aabb_sweep_node(i, L7, left, right, pmin, pmax, cmin, cmax);
-}
-
-// ---- node depths (for the traversal numbering) ----------------------------------------------
-__global__ __launch_bounds__(kBT) void depth_sweep_kernel(const int *parent, int ni, int *depth, int *changed) {
-  const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= ni || depth[i] >= 0) return;
-  const int pd = depth[parent[i]];
-  if (pd >= 0) {
-    depth[i] = pd + 1;
-    *changed = 1;
+  if (i >= ni) return;
+  const int mine = fin[i];
+  if (mine <= sweep - 2) return;
+  aabb_sweep_node(i, L7, left, right, pmin, pmax, cmin, cmax);
+  if (mine > sweep) {
+    // (a child finishing in this very sweep stores `sweep`, which is not < sweep: no race)
+    const int kl = left[i], kr = right[i];
+    const bool fl = kl <= -2 || fin[kl] < sweep, fr = kr <= -2 || fin[kr] < sweep;
+    if (fl && fr) fin[i] = sweep;
   }
 }
 
-__global__ __launch_bounds__(kBT) void depth_keys_kernel(const int *depth, int ni, unsigned *keys, int *vals, int *maxdepth) {
+// ---- node depths (for the traversal numbering) ----------------------------------------------
+// depth of every inner node = number of ancestors (walk up the parent links), written as the
+// sort key of the traversal numbering; also the maximum depth
+__global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int ni, unsigned *keys, int *vals, int *maxdepth) {
   const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= ni) return;
-  keys[i] = (unsigned)depth[i];
-  vals[i] = i;
-  atomicMax(maxdepth, depth[i]);
+  int d = 0;
+  if (i < ni) {
+    for (int p = parent[i]; p >= 0; p = parent[p]) ++d;
+    keys[i] = (unsigned)d;
+    vals[i] = i;
+  }
+  for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(maxdepth, d);
 }
 
 __global__ __launch_bounds__(kBT) void invert_kernel(const int *order, int ni, int *trav_of) {
@@ -393,8 +402,7 @@ constexpr int kSmallMax = 16384;   // digit totals fit the packed 16-bit counter
 constexpr int kSmallE = 17;        // consecutive elements a thread owns in a sort pass (odd: LDS stride)
 
 struct SmallArgs {
-  const float *sph7_in;   // [n][7] input, host-pinned (read once, streaming)
-  float *sph7;            // [n][7] device copy (the gather after the sort reads it)
+  const float *sph7;      // [n][7] input spheres (device memory: a scene is device resident)
   int n, sweeps;
   GpuBvhOut o;
   float *centres;   // [n][3]
@@ -488,22 +496,6 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
   unsigned long long *stamps = (unsigned long long *)(a.result + 16);
 #define STAMP(k) do { if (tid == 0) stamps[k] = wall_clock64(); } while (0)
   STAMP(0);
-  // 0. the input spheres come straight from host-pinned memory (one coalesced streaming read)
-  if (a.sph7_in != a.sph7) {
-    const float4 *in4 = (const float4 *)a.sph7_in;   // (both blocks are padded to whole float4s)
-    float4 *out4 = (float4 *)a.sph7;
-    const int n4 = (7 * n + 3) / 4;
-    for (int j0 = 0; j0 < n4; j0 += 8 * kSmallNT) {   // 8 loads in flight per lane: PCIe latency, not bandwidth
-      float4 t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (j0 + u * kSmallNT + tid < n4) t[u] = in4[j0 + u * kSmallNT + tid];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (j0 + u * kSmallNT + tid < n4) out4[j0 + u * kSmallNT + tid] = t[u];
-    }
-  }
-  __syncthreads();
   // 1. centres and their bounds
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = tid; i < n; i += kSmallNT) {
@@ -754,7 +746,7 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
 namespace {
 // device scratch of one build, carved from one caller-provided block (256-byte aligned pieces)
 struct ScratchLayout {
-  size_t input, centres, partial, bounds, k0, k1, v0, v1, counts, bufmin, bufmax, depth, trav, flags, box4, total;
+  size_t centres, partial, bounds, k0, k1, v0, v1, counts, bufmin, bufmax, depth, trav, flags, box4, total;
 };
 ScratchLayout scratch_layout(int n) {
   const size_t ni = (size_t)n - 1;
@@ -763,7 +755,6 @@ ScratchLayout scratch_layout(int n) {
   ScratchLayout l{};
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
-  l.input = carve(sizeof(float) * 7 * (size_t)n);
   l.centres = carve(sizeof(float) * 3 * (size_t)n);
   if (n <= kSmallMax) {
     l.box4 = carve(sizeof(float4) * 4 * ni);
@@ -789,29 +780,44 @@ ScratchLayout scratch_layout(int n) {
 }  // namespace
 
 size_t gpu_build_scratch_bytes(int n) { return scratch_layout(n).total; }
-// host-pinned block: 64 ints the kernels report through, then staging for a small scene's spheres
-constexpr size_t kPinnedHeader = 64 * sizeof(int);
-size_t gpu_build_pinned_bytes() { return kPinnedHeader + sizeof(float) * 7 * (size_t)kSmallMax + 16; }
+// host-pinned block the kernels report through: [0] max depth, [1] "depth changed" flag,
+// [4..11] the root's traversal record, [16..] phase timestamps of the small-scene kernel
+size_t gpu_build_pinned_bytes() { return 64 * sizeof(int); }
 
-// Builds everything from n spheres in host memory.  All output arrays, the scratch block
+namespace {
+__global__ __launch_bounds__(kBT) void copy_words_kernel(const uint4 *src, uint4 *dst, size_t n16) {
+  for (size_t i = blockIdx.x * (size_t)kBT + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBT) dst[i] = src[i];
+}
+}  // namespace
+// Device copy of a host-PINNED buffer by a kernel that reads it over PCIe (bytes rounded up to 16;
+// both buffers padded accordingly).  hipMemcpy of a few hundred KB of pageable memory takes 7 ms
+// on this stack, its pinned/DMA variant 0.3 ms, this ~20 us.
+hipError_t gpu_copy_from_pinned(void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t st) {
+  const size_t n16 = (bytes + 15) / 16;
+  if (n16 == 0) return hipSuccess;
+  const size_t blocks = (n16 + kBT - 1) / kBT;
+  hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(kBT), 0, st,
+                     (const uint4 *)src_pinned, (uint4 *)dst_dev, n16);
+  return hipGetLastError();
+}
+
+// Builds everything from n spheres in device memory.  All output arrays, the scratch block
 // (gpu_build_scratch_bytes(n)) and the host-pinned block (gpu_build_pinned_bytes()) are allocated by
 // the caller (sizes in rt_device.hpp: GpuBvhOut).  Returns after the stream has drained, with the
 // tree height and the root's box.
-hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &o, char *scratch, char *pinned, hipStream_t st,
+hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char *scratch, char *pinned, hipStream_t st,
                          int *height_out, float root_lo[3], float root_hi[3]) {
   const int ni = n - 1;
   const int nb_n = cdiv(n, kBT), nb_ni = cdiv(ni, kBT);
   const int red_blocks = nb_n < 1024 ? nb_n : 1024;
   const ScratchLayout l = scratch_layout(n);
-  float *centres = (float *)(scratch + l.centres), *sph7_dev = (float *)(scratch + l.input);
+  float *centres = (float *)(scratch + l.centres);
   int *result = (int *)pinned;
   const float *root = (const float *)(result + 4);
 
   if (n <= kSmallMax) {
-    // the whole build in one workgroup / one launch; the kernel pulls the spheres from the pinned block
-    float *stage = (float *)(pinned + kPinnedHeader);
-    memcpy(stage, sph7_host, sizeof(float) * 7 * (size_t)n);
-    SmallArgs a{stage, sph7_dev, n, (int)log2f((float)n) + 2, o, centres, (float4 *)(scratch + l.box4),
+    // the whole build in one workgroup / one launch
+    SmallArgs a{sph7_dev, n, (int)log2f((float)n) + 2, o, centres, (float4 *)(scratch + l.box4),
                 (int *)(scratch + l.v0), (int *)(scratch + l.trav), result};
     BVH_HIP(hipFuncSetAttribute((const void *)bvh_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * (int)sizeof(unsigned) * kSmallMax));
@@ -831,7 +837,6 @@ hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &o, char
     }
     return hipSuccess;
   }
-  BVH_HIP(hipMemcpyAsync(sph7_dev, sph7_host, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice, st));
   float *partial = (float *)(scratch + l.partial), *bounds = (float *)(scratch + l.bounds);
   unsigned *keys[2] = {(unsigned *)(scratch + l.k0), (unsigned *)(scratch + l.k1)}, *counts = (unsigned *)(scratch + l.counts);
   int *vals[2] = {(int *)(scratch + l.v0), (int *)(scratch + l.v1)};
@@ -859,28 +864,20 @@ hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &o, char
   }
   BVH_HIP(hipMemsetAsync(pmin, 0, sizeof(float) * 3 * (size_t)ni, st));
   BVH_HIP(hipMemsetAsync(pmax, 0, sizeof(float) * 3 * (size_t)ni, st));
+  BVH_HIP(hipMemsetAsync(depth, 0x7F, sizeof(int) * (size_t)ni, st));   // fin[] = 0x7f7f7f7f (borrowed: depth[] is set later)
   for (int s = 0; s < sweeps; ++s) {
-    hipLaunchKernelGGL(aabb_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax);
+    hipLaunchKernelGGL(aabb_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax,
+                       depth, s);
     float *t0 = pmin, *t1 = pmax;
     pmin = cmin; pmax = cmax; cmin = t0; cmax = t1;
   }
   // (after the loop pmin/pmax point at the newest boxes == o.bmin/o.bmax by the parity choice above)
-  // 5. depths: top-down sweeps until nothing changes
-  BVH_HIP(hipMemsetAsync(depth, 0xFF, sizeof(int) * (size_t)ni, st));
-  BVH_HIP(hipMemsetAsync(depth, 0, sizeof(int), st));   // root
-  for (int round = 0; round < 16; ++round) {
-    BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
-    for (int s = 0; s < 8; ++s)
-      hipLaunchKernelGGL(depth_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, depth, flags);
-    BVH_HIP(hipMemcpyAsync(result + 1, flags, sizeof(int), hipMemcpyDeviceToHost, st));
-    BVH_HIP(hipStreamSynchronize(st));
-    if (!result[1]) break;
-  }
-  // 6. traversal numbering: stable sort of the inner nodes by depth (6 bits)
+  // 5./6. depths by walking up the parent links; traversal numbering: stable sort of the inner
+  // nodes by depth
   BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
-  hipLaunchKernelGGL(depth_keys_kernel, dim3(nb_ni), dim3(kBT), 0, st, depth, ni, keys[0], vals[0], flags + 1);
+  hipLaunchKernelGGL(depth_walk_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, keys[0], vals[0], flags + 1);
   cur = 0;
-  for (int shift = 0; shift < 8; shift += 2) {
+  for (int shift = 0; shift < 6; shift += 2) {   // depth <= 30 key bits + 26 index bits < 64
     BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], ni, shift, counts, st));
     cur ^= 1;
   }

@@ -62,10 +62,11 @@ struct GpuBvhOut {
   float4 *sph, *col;         // [n]
 };
 size_t gpu_build_scratch_bytes(int n);   // device scratch one build of n spheres needs
-size_t gpu_build_pinned_bytes();         // host-pinned block: result words + staging for small scenes
-// `sph7_host`: the n spheres in (pageable) host memory; `scratch`, `pinned`: blocks of the sizes
-// above.  Synchronises the stream; returns the tree height and the root's box.
-hipError_t gpu_build_bvh(const float *sph7_host, int n, const GpuBvhOut &out, char *scratch, char *pinned, hipStream_t stream,
+hipError_t gpu_copy_from_pinned(void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t stream);
+size_t gpu_build_pinned_bytes();         // host-pinned block the build kernels report through
+// `sph7_dev`: the n spheres in device memory; `scratch`, `pinned`: blocks of the sizes above.
+// Synchronises the stream; returns the tree height and the root's box.
+hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, char *scratch, char *pinned, hipStream_t stream,
                          int *height_out, float root_lo[3], float root_hi[3]);
 
 hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream);
