@@ -389,6 +389,8 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault) != hipSuccess)
     return 7;
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), kStageBytes, hipHostMallocDefault) != hipSuccess) return 7;
+  rtk::warm_render_kernels();
+  rtk::warm_build_kernels();
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
   *out = ctx.release();
   return 0;

@@ -780,6 +780,10 @@ ScratchLayout scratch_layout(int n) {
 }  // namespace
 
 size_t gpu_build_scratch_bytes(int n) { return scratch_layout(n).total; }
+void warm_build_kernels() {   // see warm_render_kernels
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void *)bvh_small_kernel);
+}
 // host-pinned block the kernels report through: [0] max depth, [1] "depth changed" flag,
 // [4..11] the root's traversal record, [16..] phase timestamps of the small-scene kernel
 size_t gpu_build_pinned_bytes() { return 64 * sizeof(int); }

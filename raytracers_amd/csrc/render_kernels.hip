@@ -756,6 +756,15 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   }
 }
 
+// Loads this file's code object and resolves the default kernels (HIP loads modules lazily, at
+// the first launch: ~0.5 ms that would otherwise land in the first timed frame).
+void warm_render_kernels() {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<512, true, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<512, false, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)tile_order_kernel);
+}
+
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream) {
   const size_t total = (size_t)rows_local * w;

@@ -61,6 +61,8 @@ struct GpuBvhOut {
   float4 *nodes64;           // [4*(n-1)]
   float4 *sph, *col;         // [n]
 };
+void warm_render_kernels();
+void warm_build_kernels();
 size_t gpu_build_scratch_bytes(int n);   // device scratch one build of n spheres needs
 hipError_t gpu_copy_from_pinned(void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t stream);
 size_t gpu_build_pinned_bytes();         // host-pinned block the build kernels report through

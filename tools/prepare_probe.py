@@ -13,3 +13,16 @@ for name in ("rgbbox", "irreg"):
         ctx.sync()
         ts.append(1e6 * (time.perf_counter() - t0))
     print(name, " ".join(f"{t:.0f}" for t in ts), "us")
+import numpy as np
+for name in ("rgbbox", "irreg"):
+    ctx2 = api.Context(0)
+    sc = ctx2.scene(name)
+    ps = api.prepare_scene(1000, 1000, sc)
+    ts = []
+    buf = ctx2.alloc_i32(1000 * 1000)
+    for i in range(6):
+        t0 = time.perf_counter()
+        api.render_into(buf.ptr, 1000, 1000, ps)
+        ctx2.sync()
+        ts.append(1e6 * (time.perf_counter() - t0))
+    print("render", name, " ".join(f"{t:.0f}" for t in ts), "us")
