@@ -43,6 +43,7 @@ struct rt_context {
   int grid_div = 1;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups
   int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
+  int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
   // wave stops at its first out-of-range ticket), so the next launch's base is known.
@@ -324,7 +325,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
         std::memcpy(o.cam, &p.cam, sizeof o.cam);
         o.ntiles = p.nchunks;
         RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
-        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(o.ntiles)));
+        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * (static_cast<size_t>(o.ntiles) + 16)));
         RT_HIP(ctx, hipMemsetAsync(o.cost, 0, sizeof(int) * static_cast<size_t>(o.ntiles), ctx->stream));
         ps->orders.push_back(o);
         to = &ps->orders.back();
@@ -335,6 +336,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
       const bool rerecord = !to->valid || ctx->adaptive_order == 2;
       p.cost = rerecord ? to->cost : nullptr;
       p.order = to->valid ? to->order : nullptr;
+      p.deep_class = ctx->deep_class;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
@@ -473,6 +475,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->gpu_build = v != 0;
   } else if (k == "adaptive_order") {
     ctx->adaptive_order = v;
+  } else if (k == "deep_class") {
+    ctx->deep_class = std::min(8, std::max(0, v));
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -777,8 +781,10 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
     // use the adaptive order of the matching view if one exists (read-only here)
     for (auto &o : ps->orders)
       if (o.h == h && o.w == w && o.part == 0 && o.nparts == 1 && o.max_depth == max_depth && o.valid &&
-          ctx->adaptive_order && o.ntiles == p.nchunks)
+          ctx->adaptive_order && o.ntiles == p.nchunks) {
         p.order = o.order;
+        p.deep_class = ctx->deep_class;
+      }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(nw);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

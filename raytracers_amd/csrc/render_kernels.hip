@@ -355,6 +355,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   int q_col0 = 0, q_row0 = 0;   // its first pixel column / local row
   int ptile = 0;           // (per lane) tile of the pixel in this slot, for the cost record
   bool exhausted = false;
+  // A wave that draws a DEEP tile (one whose longest bounce chain was long in the recorded frame)
+  // stops refilling until that tile is finished and raises its issue priority: the frame cannot
+  // end before its longest chain does, and a chain advances ~3x faster in a wave that is not
+  // busy with 63 other rays' work.
+  bool hold = false;
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   int tr_maxdepth = 0;
@@ -369,7 +374,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     if (nbox < 64 && nleaf < 64) {
       // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
-      const bool vacant = (pix < 0) & !exhausted;
+      if (hold && bal(pix >= 0) == 0ull) {   // the deep tile is finished: back to normal service
+        hold = false;
+        __builtin_amdgcn_s_setprio(0);
+      }
+      const bool vacant = (pix < 0) & !exhausted & !hold;
       const int ns = __popcll(bal(done | vacant));
       // a short box stack means idle lanes in the coming BOX operations: be more eager to start
       // new folds then (thr_shade_low applies while nbox < low_box)
@@ -415,11 +424,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
           }
         }
-        bool want = (pix < 0) & !exhausted;
+        bool want = (pix < 0) & !exhausted & !hold;
         int slot = -1;
         unsigned long long m = bal(want);
         while (m != 0ull) {            // wave-uniform loop
           if (q_next == q_end) {
+            if (hold) break;           // a deep tile is in flight: no further tickets for now
             unsigned t = 0;
             if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
             t = __builtin_amdgcn_readfirstlane(t);
@@ -431,6 +441,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             q_next = t * 64u;
             q_end = q_next + 64u;
             q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
+            if (p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
+              hold = true;
+              __builtin_amdgcn_s_setprio(3);
+            }
             const int ty = q_tile / p.tiles_x;                    // once per ticket, scalar
             q_col0 = (q_tile - ty * p.tiles_x) * 8;
             q_row0 = ty * 8;
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
         // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
         // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
-        if (p.prio_depth > 0) {
+        if (p.prio_depth > 0 && !hold) {
           const bool live = pix >= 0;
           if (bal(live && depth >= 4 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(3);
           else if (bal(live && depth >= 2 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(2);
@@ -634,6 +648,9 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, in
       acc += hist[c][kOrderThreads - 1];
     }
     class_base[kOrderClasses] = acc;
+    // first ticket of each cost class (class c = chains of 2^(7-c) .. 2^(8-c) - 1 bounces): the
+    // render kernel treats the tickets below order[ntiles + deep_class] as deep tiles
+    for (int c = 0; c <= kOrderClasses; ++c) order[ntiles + c] = class_base[c];
   }
   __syncthreads();
   int pos[kOrderClasses];

@@ -40,7 +40,8 @@ struct KParams {
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
   int low_box, thr_shade_low, low_leaf;   // policy while the box stack is short (see pooled_kernel)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
-  const int *order;      // [nchunks] ticket -> tile (nullptr: identity)
+  const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
+  int deep_class;        // tickets below order[nchunks + deep_class] are "deep" tiles (0: feature off)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
