@@ -40,7 +40,7 @@ struct rt_context {
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
-  int grid_div = 1;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups
+  int grid_div = 0;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups; 0 = by frame size
   int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
@@ -216,7 +216,9 @@ struct Plan {
 };
 
 // Decide the launch shape of the persistent family for one prepared scene.
-int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
+// `ntiles`: 8x8 tiles of the launch (grid_div == 0 picks the launch size from it: up to ~1000x1000 a
+// half-size launch keeps the waves better filled -- 5-18 % per frame --, larger frames want every wave).
+int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) {
   pl->variant = ctx->variant;
   if (pl->variant == RT_VARIANT_AUTO) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
   if (pl->variant == RT_VARIANT_PIXEL) return 0;
@@ -252,7 +254,8 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl) {
   pl->lds_sph = ls;
   pl->lds_bytes = pl->variant == RT_VARIANT_POOLED ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
                                                    : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
-  pl->grid = std::max(1, ctx->num_cu * ctx->wgs_per_cu / std::max(1, ctx->grid_div));
+  const int div = ctx->grid_div > 0 ? ctx->grid_div : (pl->variant == RT_VARIANT_POOLED && ntiles <= 32768 ? 2 : 1);
+  pl->grid = std::max(1, ctx->num_cu * ctx->wgs_per_cu / div);
   return 0;
 }
 
@@ -289,7 +292,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   }
   Plan pl{};
   if (stats) pl.variant = RT_VARIANT_PIXEL;
-  else if (int rc = make_plan(ctx, ps, &pl)) return rc;
+  else if (int rc = make_plan(ctx, ps, &pl, static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8))) return rc;
   if (pl.variant == RT_VARIANT_PIXEL) {
     RT_HIP(ctx, rtk::launch_pixel(p, stats, ctx->stream));
     return 0;
@@ -462,7 +465,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   } else if (k == "lds_sph_first") {
     ctx->lds_sph_first = v != 0;
   } else if (k == "grid_div") {
-    ctx->grid_div = std::max(1, std::min(64, v));
+    ctx->grid_div = std::max(0, std::min(64, v));
   } else if (k == "low_box") {
     ctx->low_box = std::max(0, std::min(64, v));
   } else if (k == "thr_shade_low") {
@@ -742,7 +745,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   Plan pl{};
   const int saved = ctx->variant;
   ctx->variant = RT_VARIANT_POOLED;
-  int rc = make_plan(ctx, ps, &pl);
+  int rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8));
   ctx->variant = saved;
   if (rc) return rc;
   pl.waves = 8;   // the instrumented instantiation is the 512-thread one
