@@ -356,6 +356,8 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
 }  // namespace
 
 // ------------------------------------------------------------------------------------ context
+extern "C" void rt_context_destroy(rt_context *ctx);
+
 extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream, int use_caller_stream) {
   if (!out) return 1;
   *out = nullptr;
@@ -375,6 +377,11 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   ctx->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 5;
+  // from here on a failure releases whatever was created so far
+  auto bail = [&](int code) {
+    rt_context_destroy(ctx.release());
+    return code;
+  };
   ctx->num_cu = prop.multiProcessorCount;
   ctx->lds_bytes = static_cast<int>(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
                                                                            : prop.sharedMemPerBlock);
@@ -382,18 +389,18 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (use_caller_stream) {
     ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL is a valid handle: the default stream
   } else {
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return 6;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(6);
     ctx->own_stream = true;
   }
-  if (hipMalloc(reinterpret_cast<void **>(&ctx->queue_dev), 256) != hipSuccess) return 7;
-  if (hipMemset(ctx->queue_dev, 0, 256) != hipSuccess) return 7;
-  if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return 7;
-  if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return 7;
-  if (hipMalloc(reinterpret_cast<void **>(&ctx->arena), kArenaGranules * kGranule) != hipSuccess) return 7;
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->queue_dev), 256) != hipSuccess) return bail(7);
+  if (hipMemset(ctx->queue_dev, 0, 256) != hipSuccess) return bail(7);
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return bail(7);
+  if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return bail(7);
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->arena), kArenaGranules * kGranule) != hipSuccess) return bail(7);
   ctx->arena_used.assign(kArenaGranules, 0);
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault) != hipSuccess)
-    return 7;
-  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), kStageBytes, hipHostMallocDefault) != hipSuccess) return 7;
+    return bail(7);
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), kStageBytes, hipHostMallocDefault) != hipSuccess) return bail(7);
   rtk::warm_render_kernels();
   rtk::warm_build_kernels();
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);

@@ -288,6 +288,17 @@ def test_stacked_parts_assemble_in_one_kernel(R, ctx, nparts):
     R.place_parts(ctx, h, w, nparts, pad, stacked.data_ptr(), image.data_ptr())
     ctx.sync()
     assert int((image.cpu().numpy() != want).sum()) == 0
+    # strided form: each part's rows sit inside a longer per-rank record (several frames per gather)
+    lead, stride = 13, pad * w + 29
+    rec = torch.full((nparts, stride), -9, dtype=torch.int32, device="cuda")
+    rec[:, lead:lead + pad * w] = stacked.view(nparts, pad * w)
+    image.fill_(-1)
+    torch.cuda.synchronize()
+    R.place_parts(ctx, h, w, nparts, pad, rec.data_ptr() + 4 * lead, image.data_ptr(), part_stride=stride)
+    ctx.sync()
+    assert int((image.cpu().numpy() != want).sum()) == 0
+    with pytest.raises(Exception):   # a stride shorter than the largest part is refused
+        R.place_parts(ctx, h, w, nparts, pad, rec.data_ptr(), image.data_ptr(), part_stride=w)
 
 
 def test_sharded_renderer_single_rank_on_torch_stream(R):
