@@ -23,10 +23,11 @@ call (futhark/ray.fut:130).  Ray and box/sphere-test counts come from an instrum
 and are cross-checked against the oracle-derived constants below.
 
 The JSON line also carries
-  roofline      for the dominant kernel (the rgbbox launch of persistent_kernel): ALGORITHMIC
-                bytes per launch (32 B per box test + 16 B per sphere test + 4 B per pixel,
-                SURVEY.md 8d) / mean launch duration measured with events on the launch stream
-                inside the timed region, against the 8 TB/s HBM3E peak;
+  roofline      for the dominant kernel (pooled_kernel): ALGORITHMIC bytes (32 B per box test +
+                16 B per sphere test + 4 B per pixel) of the timed region's launches /
+                its wall time, against the 8 TB/s HBM3E peak; per_launch = the dominant launch's
+                bytes / its mean duration measured with events on the launch stream inside the timed
+                region (stretched by the other frames in flight); valu = the VALU-issue fraction;
   cpu_baseline  the CPU oracle (a port of the reference's Futhark program, OpenMP over rows)
                 timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -282,18 +283,26 @@ def main():
                        "options": opts_pipe, "frames_in_flight": S,
                        "partition": f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per step"
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
-            "roofline": {"bound": "hbm", "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
-                         + f" on {dscene} {dw}x{dh}",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm",
+                         "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
+                                   + " (the launches of " + " and ".join(f"{s} {w}x{h}" for s, h, w in frames) + ")",
+                         # launches of up to frames_in_flight frames share the GPU, so the kernel's rate is
+                         # what all of them together get through per second
+                         "achieved": sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * args.steps / elapsed / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "traffic": None,
-                         "aggregate_frac": sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * args.steps
-                                           / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved = algorithmic bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) / mean "
-                                 "launch time of the dominant kernel in the timed region (launches of up to "
-                                 "frames_in_flight frames overlap, which stretches each one: aggregate_frac = "
-                                 "algorithmic bytes of all launches / wall time; frac_one_frame_at_a_time = the same "
-                                 "launch alone on the GPU); the scene is LDS/L2 resident so real HBM traffic is a "
-                                 "few MB per frame"},
+                         "per_launch": {"kernel": f"{dscene} {dw}x{dh}", "alg_bytes": per_scene[dkey]["alg_bytes_per_launch"],
+                                        "avg_launch_ms": kern_ms[dom], "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                        "avg_launches_in_flight": sum(kern_ms) * args.steps / (elapsed * 1e3),
+                                        "note": "HIP events around each launch on its own stream inside the timed region; "
+                                                "the launches in flight stretch one another"},
+                         "note": "achieved = ALGORITHMIC bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) of all launches "
+                                 "in the timed region / its wall time; per_launch = the dominant launch's bytes / its mean "
+                                 "event-bracketed duration while the other frames in flight share the GPU; "
+                                 "frac_one_frame_at_a_time = the same launch alone on the GPU.  The scene is LDS/L2 "
+                                 "resident: measured HBM traffic (traffic, bytes per step from the PMC passes) is a few MB, so "
+                                 "the nominal HBM roofline can be exceeded; what binds is VALU issue (valu)"},
             "per_scene": per_scene,
             "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
                                   "note": "README.md:50 render times / oracle ray counts; different hardware"},
@@ -303,9 +312,9 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 trj = json.load(f)
-            tr = trj.get(f"pooled_kernel {dscene} {dw}x{dh}")
-            if tr and args.variant in (0, 3) and world == 1:
-                out["roofline"]["traffic"] = tr["hbm_bytes"]
+            trs = [trj.get(f"pooled_kernel {s} {w}x{h}", {}).get("hbm_bytes") for s, h, w in frames]
+            if all(trs) and args.variant in (0, 3) and world == 1:
+                out["roofline"]["traffic"] = sum(trs)   # HBM bytes of one step's launches
             # what actually bounds this kernel: VALU issue.  wave-instructions of all launches of a
             # step (PMC SQ_INSTS_VALU at the bench's launch size) / step time, against one VALU
             # wave64 instruction per 4 clocks per SIMD at the 2.4 GHz peak clock

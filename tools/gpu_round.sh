@@ -19,11 +19,12 @@ echo "== reference harness (futhark/main.c, unmodified) on our library"
 for s in rgbbox irreg; do timeout 120 ./oracle/_ref/futhark_main -s $s -n 1000 -m 1000 2>&1 | grep -E "construction|Rendering"; done
 } > $OUT/rtbench.log 2>&1
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-serial-extra > $OUT/rocprof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-serial-extra > $OUT/rocprof_bench.log 2>&1
 cd $OLDPWD
 bash tools/gpu_pmc.sh $TAG/pmc "3" "rgbbox irreg" > $OUT/pmc.log 2>&1
 PMC_FIRST_ONLY=1 EXTRA_OPTS="-o grid_div=8" bash tools/gpu_pmc.sh $TAG/pmc_gd8 "3" "rgbbox irreg" > $OUT/pmc_gd8.log 2>&1
 python tools/make_traffic_json.py $OUT/pmc $OUT/pmc_gd8 > $OUT/traffic.json 2> $OUT/traffic.err
-python tools/rocpd_summary.py $OUT/prof_bench > $OUT/summary_bench_kernel_trace.txt 2>&1
+python tools/rocpd_summary.py --last 50 $OUT/prof_bench > $OUT/summary_bench_kernel_trace.txt 2>&1
+grep '^{"metric"' $OUT/rocprof_bench.log > $OUT/bench_under_rocprof.json
 python tools/rocpd_summary.py $OUT/pmc/*_p[0-9] > $OUT/summary_pmc.txt 2>&1
 echo round done

@@ -3,7 +3,11 @@
 under profiles/: per-kernel call count / total / mean / min / max duration from the
 kernel-trace, and (when present) the per-kernel mean of every PMC counter.
 
-  tools/rocpd_summary.py <rocprof_out_dir> [more dirs ...] > profiles/<name>.txt
+  tools/rocpd_summary.py [--last N] <rocprof_out_dir> [more dirs ...] > profiles/<name>.txt
+
+--last N adds, per kernel, the mean over its LAST N dispatches in time order: for a bench.py
+trace these are the N timed steps (the launches before them -- lane set-up and warm-up -- run at
+a different degree of overlap, so the all-dispatch mean is not the timed region's).
 """
 import collections
 import csv
@@ -13,18 +17,26 @@ import sys
 
 
 def main():
-    for d in sys.argv[1:]:
-        print(f"== {d}")
+    args = sys.argv[1:]
+    last = 0
+    if args and args[0] == "--last":
+        last = int(args[1])
+        args = args[2:]
+    for d in args:
+        print(f"== {os.path.relpath(d)}")
         kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
-        dur = collections.defaultdict(list)
+        timed = collections.defaultdict(list)
         for f in kt:
             for r in csv.DictReader(open(f)):
-                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                timed[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        dur = {k: [x[1] for x in sorted(v)] for k, v in timed.items()}
         if dur:
             tot = sum(sum(v) for v in dur.values())
-            print("kernel-trace: name | calls | total_ns | mean_ns | min_ns | max_ns | % of GPU time")
+            print("kernel-trace: name | calls | total_ns | mean_ns | min_ns | max_ns | % of GPU time"
+                  + (f" | mean_ns of the last {last} dispatches" if last else ""))
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-                print(f"  {k[:90]} | {len(v)} | {sum(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | {100.0 * sum(v) / tot:.2f}")
+                tail = f" | {sum(v[-last:]) / len(v[-last:]):.0f}" if last else ""
+                print(f"  {k[:90]} | {len(v)} | {sum(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | {100.0 * sum(v) / tot:.2f}{tail}")
         cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         acc = collections.defaultdict(list)
         for f in cc:
