@@ -77,38 +77,60 @@ def bytes_alg(box, sph, h, w):
     return 32 * box + 16 * sph + 4 * h * w
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes show 256 hardware threads but grant 16 CPUs' worth of time; 256 OpenMP threads
+    on such a quota run 4-5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())         # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(frames, budget_s=12.0):
     """Times the CPU oracle (tests/oracle_lib.py -> oracle/ray_oracle.c) on the same frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     scenes = [(O.OracleScene(s), h, w) for s, h, w in frames]
-    cores = int(O.lib().orc_num_threads())
+    cores = min(effective_cpus(), int(O.lib().orc_num_threads()))
     rays = 0
     reps = 0
     t0 = time.perf_counter()
     while True:
         for sc, h, w in scenes:
-            _, cnt = sc.render(h, w, threads=0)
+            _, cnt = sc.render(h, w, threads=cores)
             rays += cnt["rays"]
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 5:
+        if time.perf_counter() - t0 > budget_s or reps >= 200:
             break
     dt = time.perf_counter() - t0
     out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
            "sample": f"{reps} full frame(s) of each of {'+'.join(f'{s} {w}x{h}' for s, h, w in frames)}, "
-                     f"OpenMP dynamic over rows on all {cores} host threads, {dt:.1f} s"}
+                     f"OpenMP dynamic over row chunks on {cores} threads (= the CPUs this process is granted: "
+                     f"affinity {len(os.sched_getaffinity(0))}, cgroup quota applied), {dt:.1f} s"}
     # second comparator: the reference's RUST algorithm (different BVH / epsilon, different image;
     # timing only -- oracle/rust_algo_port.c), same frames, same threads
     try:
         rs = [(O.RustAlgoScene(s), h, w) for s, h, w in frames if s in ("rgbbox", "irreg")]
         if rs:
-            rrays, t1 = 0, time.perf_counter()
-            for _ in range(2):
+            rrays, rreps, t1 = 0, 0, time.perf_counter()
+            while time.perf_counter() - t1 < budget_s / 2 and rreps < 200:
                 for sc, h, w in rs:
-                    rrays += sc.render(h, w, threads=0)[1]
+                    rrays += sc.render(h, w, threads=cores)[1]
+                rreps += 1
             rdt = time.perf_counter() - t1
             out["rust_algorithm"] = {"value": rrays / rdt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-                                     "sample": f"2 frames of each scene, {rdt:.1f} s",
+                                     "sample": f"{rreps} frames of each scene, {rdt:.1f} s",
                                      "note": "C restatement of rust/src/lib.rs (median-split BVH, eps 0.001): timing only"}
     except Exception as e:   # the baseline must never take the bench line down
         out["rust_algorithm"] = {"error": str(e)}
