@@ -256,6 +256,9 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) 
                                                    : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
   const int div = ctx->grid_div > 0 ? ctx->grid_div : (pl->variant == RT_VARIANT_POOLED && ntiles <= 32768 ? 2 : 1);
   pl->grid = std::max(1, ctx->num_cu * ctx->wgs_per_cu / div);
+  // workgroups go round-robin to the 8 XCDs: keep their number a multiple of 8 so that no XCD carries
+  // one more persistent workgroup than the others (grid_div=12 -> 42 workgroups measured +15 %)
+  if (pl->grid >= 8) pl->grid -= pl->grid % 8;
   return 0;
 }
 
