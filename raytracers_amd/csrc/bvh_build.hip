@@ -129,10 +129,10 @@ __global__ __launch_bounds__(kBT) void morton_kernel(const float *centres, const
   if (i < n) morton_elem(i, centres, bounds, keys, vals);
 }
 
-// ---- stable LSD radix sort of (key, val), 2 bits per pass ---------------------------------
+// ---- stable LSD radix sort of (key, val), 4 bits per pass ---------------------------------
 // Thread t of a block owns kSortE CONSECUTIVE elements, so thread order == element order and a
-// block-wide exclusive scan of per-thread digit counts gives stable ranks.  Counts of the four
-// digit values travel packed in one u64 (16 bits each).
+// block-wide exclusive scan of per-thread digit counts gives stable ranks.  Counts of the 16
+// digit values travel packed 16 bits each in four u64 words.
 template <int NT = kBT>
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total) {
   __shared__ unsigned long long wave_sum[NT / 64];
@@ -156,19 +156,36 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
   return base + incl - v;
 }
 
+// digit counts of kSortE elements, 16 bits per digit value, four values per u64 word
+constexpr int kSortBits = 4, kSortDigits = 1 << kSortBits, kSortWords = kSortDigits / 4;
+struct DigitCounts {
+  unsigned long long w[kSortWords];
+};
+__device__ __forceinline__ void digit_add(DigitCounts &c, unsigned d) {
+#pragma unroll
+  for (int j = 0; j < kSortWords; ++j) c.w[j] += (d >> 2) == (unsigned)j ? 1ull << (16 * (d & 3u)) : 0ull;
+}
+__device__ __forceinline__ unsigned digit_get(const DigitCounts &c, unsigned d) {
+  unsigned long long v = 0;
+#pragma unroll
+  for (int j = 0; j < kSortWords; ++j) v = (d >> 2) == (unsigned)j ? c.w[j] : v;
+  return (unsigned)((v >> (16 * (d & 3u))) & 0xffffull);
+}
+
 __global__ __launch_bounds__(kBT) void sort_count_kernel(const unsigned *keys, int n, int shift, unsigned *block_counts,
                                                          int nblocks) {
   const int base = (blockIdx.x * kBT + threadIdx.x) * kSortE;
-  unsigned long long cnt = 0;
+  DigitCounts cnt = {};
 #pragma unroll
   for (int e = 0; e < kSortE; ++e)
-    if (base + e < n) cnt += 1ull << (16 * ((keys[base + e] >> shift) & 3u));
-  unsigned long long tot;
-  (void)block_excl_scan_u64(cnt, &tot);
-  if (threadIdx.x < 4) block_counts[threadIdx.x * nblocks + blockIdx.x] = (unsigned)((tot >> (16 * threadIdx.x)) & 0xffffull);
+    if (base + e < n) digit_add(cnt, (keys[base + e] >> shift) & (kSortDigits - 1));
+  DigitCounts tot;
+#pragma unroll
+  for (int j = 0; j < kSortWords; ++j) (void)block_excl_scan_u64(cnt.w[j], &tot.w[j]);
+  if (threadIdx.x < kSortDigits) block_counts[threadIdx.x * nblocks + blockIdx.x] = digit_get(tot, threadIdx.x);
 }
 
-// exclusive scan of m counters by one block (m = 4 * nblocks, digit-major = the order the
+// exclusive scan of m counters by one block (m = 16 * nblocks, digit-major = the order the
 // sorted array is laid out in)
 __global__ __launch_bounds__(kBT) void scan_small_kernel(unsigned *data, int m) {
   __shared__ unsigned carry_s;
@@ -202,25 +219,26 @@ __global__ __launch_bounds__(kBT) void sort_scatter_kernel(const unsigned *keys_
   const int base = (blockIdx.x * kBT + threadIdx.x) * kSortE;
   unsigned k[kSortE];
   int v[kSortE];
-  unsigned long long cnt = 0;
+  DigitCounts cnt = {};
 #pragma unroll
   for (int e = 0; e < kSortE; ++e) {
     if (base + e < n) {
       k[e] = keys_in[base + e];
       v[e] = vals_in[base + e];
-      cnt += 1ull << (16 * ((k[e] >> shift) & 3u));
+      digit_add(cnt, (k[e] >> shift) & (kSortDigits - 1));
     }
   }
-  unsigned long long tot;
-  unsigned long long rank = block_excl_scan_u64(cnt, &tot);   // per digit: elements of this block before this thread
+  DigitCounts rank, tot;   // per digit: elements of this block before this thread
+#pragma unroll
+  for (int j = 0; j < kSortWords; ++j) rank.w[j] = block_excl_scan_u64(cnt.w[j], &tot.w[j]);
 #pragma unroll
   for (int e = 0; e < kSortE; ++e) {
     if (base + e < n) {
-      const unsigned d = (k[e] >> shift) & 3u;
-      const unsigned pos = block_offsets[d * nblocks + blockIdx.x] + (unsigned)((rank >> (16 * d)) & 0xffffull);
+      const unsigned d = (k[e] >> shift) & (kSortDigits - 1);
+      const unsigned pos = block_offsets[d * nblocks + blockIdx.x] + digit_get(rank, d);
       keys_out[pos] = k[e];
       vals_out[pos] = v[e];
-      rank += 1ull << (16 * d);
+      digit_add(rank, d);
     }
   }
 }
@@ -730,7 +748,7 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
                      hipStream_t st) {
   const int nblocks = cdiv(n, kBT * kSortE);
   hipLaunchKernelGGL(sort_count_kernel, dim3(nblocks), dim3(kBT), 0, st, kin, n, shift, counts, nblocks);
-  hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, 4 * nblocks);
+  hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, kSortDigits * nblocks);
   hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBT), 0, st, kin, vin, n, shift, counts, nblocks, kout, vout);
   return hipGetLastError();
 }
@@ -767,7 +785,7 @@ ScratchLayout scratch_layout(int n) {
     l.k1 = carve(sizeof(unsigned) * (size_t)n);
     l.v0 = carve(sizeof(int) * (size_t)n);
     l.v1 = carve(sizeof(int) * (size_t)n);
-    l.counts = carve(sizeof(unsigned) * 4 * sort_blocks + 16);
+    l.counts = carve(sizeof(unsigned) * kSortDigits * sort_blocks + 16);
     l.bufmin = carve(sizeof(float) * 3 * ni);
     l.bufmax = carve(sizeof(float) * 3 * ni);
     l.depth = carve(sizeof(int) * ni);
@@ -852,7 +870,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   hipLaunchKernelGGL(morton_kernel, dim3(nb_n), dim3(kBT), 0, st, centres, bounds, n, keys[0], vals[0]);
   // 2. stable sort by the 30-bit key (15 passes of 2 bits)
   int cur = 0;
-  for (int shift = 0; shift < 30; shift += 2) {
+  for (int shift = 0; shift < 30; shift += kSortBits) {   // 8 passes of 4 bits
     BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, counts, st));
     cur ^= 1;
   }
@@ -881,7 +899,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
   hipLaunchKernelGGL(depth_walk_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, keys[0], vals[0], flags + 1);
   cur = 0;
-  for (int shift = 0; shift < 6; shift += 2) {   // depth <= 30 key bits + 26 index bits < 64
+  for (int shift = 0; shift < 6; shift += kSortBits) {   // depth <= 30 key bits + 26 index bits < 64: 2 passes
     BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], ni, shift, counts, st));
     cur ^= 1;
   }
