@@ -212,6 +212,31 @@ def test_tiny_and_degenerate_scenes(R, ctx, n, kind):
     ctx.set_variant(0)
 
 
+def test_axis_aligned_rays_and_nan_slabs(R, ctx):
+    """A camera on the z axis over a grid whose box faces lie on x = 0 and y = 0: the centre
+    column / row of an even-sized image gets a direction component of exactly 0 (inverse = inf),
+    and (face - origin) * inf = 0 * inf = NaN in aabb_hit.  fmaxf / fminf must drop the NaN and
+    the swap must follow the SIGN of the inverse, exactly as the reference does (ray.fut:53-70)."""
+    g = np.array([-9.0, -3.0, 3.0, 9.0], np.float32)
+    xs, ys, zs = np.meshgrid(g, g, np.array([-6.0, 0.0, 6.0], np.float32), indexing="ij")
+    n = xs.size
+    s = np.zeros((n, 7), np.float32)
+    s[:, 0], s[:, 1], s[:, 2] = xs.ravel(), ys.ravel(), zs.ravel()
+    s[:, 3:6] = np.linspace(0.4, 1.0, 3 * n, dtype=np.float32).reshape(n, 3)
+    s[:, 6] = 3.0
+    lf, la, fov = (0.0, 0.0, 40.0), (0.0, 0.0, 0.0), 40.0
+    orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
+    cam = orc.camera_floats(64, 64)
+    # the premise: the centre column's primary direction has x == 0 exactly
+    assert cam[3] + np.float32(0.5) * cam[6] - cam[0] == 0.0
+    ref, _ = orc.render(64, 64)
+    for variant in (1, 2, 3):
+        ctx.set_variant(variant)
+        ps = R.prepare_scene(64, 64, ctx.scene_from_spheres(s, lf, la, fov))
+        assert int((R.render(64, 64, ps) != ref).sum()) == 0, variant
+    ctx.set_variant(0)
+
+
 # ---------------------------------------------------------------- work counters -----------
 @pytest.mark.parametrize("scene,h", [("rgbbox", 200), ("irreg", 200), ("rgbbox", 1000), ("irreg", 1000)])
 def test_work_counters_match_oracle(R, ctx, scene, h):
