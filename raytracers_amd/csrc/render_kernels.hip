@@ -362,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   bool hold = false;
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
-  int tr_maxdepth = 0;
+  int tr_maxdepth = 0, tr_maxbox = 0, tr_maxleaf = 0;
   if (STATS) tr_t0 = clock64();
 
   for (;;) {
@@ -371,6 +371,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
     nbox = __builtin_amdgcn_readfirstlane(nbox);
     nleaf = __builtin_amdgcn_readfirstlane(nleaf);
+    if (STATS) {
+      tr_maxbox = nbox > tr_maxbox ? nbox : tr_maxbox;
+      tr_maxleaf = nleaf > tr_maxleaf ? nleaf : tr_maxleaf;
+    }
     if (nbox < 64 && nleaf < 64) {
       // not a full wave of work in either list: look at completed folds / vacant slots
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
@@ -595,7 +599,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         unsigned long long *rec = p.trace + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
         rec[0] = tr_t0; rec[1] = tr_exh; rec[2] = t_end;
         rec[3] = tr_ops[0]; rec[4] = tr_ops[1]; rec[5] = tr_ops[2];
-        rec[6] = (tr_items[0] << 32) | tr_items[1]; rec[7] = (unsigned long long)md;
+        rec[6] = (tr_items[0] << 32) | tr_items[1];
+        rec[7] = (unsigned long long)md | ((unsigned long long)tr_maxbox << 16) | ((unsigned long long)tr_maxleaf << 32);
       }
     }
   }

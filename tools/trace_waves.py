@@ -31,6 +31,10 @@ for name, v in (("start", start), ("queue exhausted", exh), ("end", end)):
     print(f"  {name:16s} min {v.min():9d}  p50 {int(np.median(v)):9d}  p90 {int(np.percentile(v, 90)):9d}  max {v.max():9d}")
 life = end - start
 print(f"  mean wave lifetime {life.mean():.0f} clk = {life.mean() / end.max():.2f} of the span")
+maxbox, maxleaf = (rec[:, 7] >> 16) & 0xFFFF, (rec[:, 7] >> 32) & 0xFFFF
+rec[:, 7] &= 0xFFFF
+print(f"  box stack high-water mark: max {maxbox.max()} p99 {int(np.percentile(maxbox, 99))} p50 {int(np.median(maxbox))} items"
+      f" (capacity 64*(height+3)); leaf list: max {maxleaf.max()}")
 ops = rec[:, 3:6]
 items_box, items_leaf = rec[:, 6] >> 32, rec[:, 6] & 0xFFFFFFFF
 tot = ops.sum(axis=1)
