@@ -25,11 +25,12 @@ RT_SYMBOLS = [
 FUTHARK_SYMBOLS = [
     "futhark_context_config_new", "futhark_context_config_free", "futhark_context_config_set_debugging",
     "futhark_context_config_set_logging", "futhark_context_config_set_profiling",
-    "futhark_context_config_set_device",
+    "futhark_context_config_set_device", "futhark_context_config_set_num_threads", "futhark_context_config_set_cache_file",
     "futhark_context_new", "futhark_context_free", "futhark_context_get_error", "futhark_context_sync",
-    "futhark_context_report",
+    "futhark_context_report", "futhark_context_clear_caches", "futhark_context_pause_profiling",
+    "futhark_context_unpause_profiling",
     "futhark_entry_rgbbox", "futhark_entry_irreg", "futhark_entry_prepare_scene", "futhark_entry_render",
-    "futhark_values_i32_2d", "futhark_free_i32_2d", "futhark_shape_i32_2d",
+    "futhark_values_i32_2d", "futhark_free_i32_2d", "futhark_shape_i32_2d", "futhark_new_i32_2d", "futhark_values_raw_i32_2d",
     "futhark_free_opaque_prepared_scene", "futhark_free_opaque_scene",
 ]
 

@@ -902,6 +902,9 @@ extern "C" void futhark_context_config_set_device(struct futhark_context_config 
   cfg->device = std::atoi(s);
 }
 
+extern "C" void futhark_context_config_set_num_threads(struct futhark_context_config *, int) {}
+extern "C" void futhark_context_config_set_cache_file(struct futhark_context_config *, const char *) {}
+
 extern "C" struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) {
   auto ctx = std::make_unique<futhark_context>();
   ctx->logging = cfg ? (cfg->logging | cfg->debugging) : 0;
@@ -1003,6 +1006,32 @@ extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i
   delete arr;
   return fut_fail(ctx, rc);
 }
+extern "C" struct futhark_i32_2d *futhark_new_i32_2d(struct futhark_context *ctx, const int32_t *data, int64_t dim0, int64_t dim1) {
+  if (!ctx || !ctx->rt || !data || dim0 < 0 || dim1 < 0) return nullptr;
+  auto arr = std::make_unique<futhark_i32_2d>();
+  arr->shape[0] = dim0; arr->shape[1] = dim1;
+  const int64_t bytes = static_cast<int64_t>(sizeof(int32_t)) * dim0 * dim1;
+  if (rt_device_alloc(ctx->rt, reinterpret_cast<void **>(&arr->dev), std::max<int64_t>(bytes, 4)) != 0) { fut_fail(ctx, 1); return nullptr; }
+  if (bytes > 0 && hipMemcpy(arr->dev, data, static_cast<size_t>(bytes), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)rt_device_free(ctx->rt, arr->dev);
+    ctx->pending = "futhark_new_i32_2d: host to device copy failed";
+    return nullptr;
+  }
+  return arr.release();
+}
+extern "C" int32_t *futhark_values_raw_i32_2d(struct futhark_context *, struct futhark_i32_2d *arr) { return arr ? arr->dev : nullptr; }
+extern "C" int futhark_context_clear_caches(struct futhark_context *ctx) {
+  if (!ctx || !ctx->rt) return 1;
+  if (rt_context_sync(ctx->rt)) return fut_fail(ctx, 1);
+  for (auto &im : ctx->image_pool) (void)rt_device_free(ctx->rt, im.second);
+  ctx->image_pool.clear();
+  for (auto &b : ctx->rt->pool) (void)hipFree(b.p);
+  ctx->rt->pool.clear();
+  return 0;
+}
+extern "C" void futhark_context_pause_profiling(struct futhark_context *) {}
+extern "C" void futhark_context_unpause_profiling(struct futhark_context *) {}
+
 extern "C" const int64_t *futhark_shape_i32_2d(struct futhark_context *, struct futhark_i32_2d *arr) {
   return arr ? arr->shape : nullptr;
 }

@@ -415,6 +415,25 @@ def test_futhark_abi_call_sequence(R):
         lib.futhark_free_i32_2d(fctx, img)
         lib.futhark_free_opaque_prepared_scene(fctx, ps)
         lib.futhark_free_opaque_scene(fctx, scene)
+    # the conventional rest of a Futhark library's array API: host -> device -> host round trip
+    lib.futhark_new_i32_2d.restype = vp
+    lib.futhark_new_i32_2d.argtypes = [vp, vp, C.c_int64, C.c_int64]
+    lib.futhark_shape_i32_2d.restype = C.POINTER(C.c_int64)
+    lib.futhark_shape_i32_2d.argtypes = [vp, vp]
+    lib.futhark_values_raw_i32_2d.restype = vp
+    lib.futhark_values_raw_i32_2d.argtypes = [vp, vp]
+    src = np.arange(7 * 11, dtype=np.int32).reshape(7, 11)
+    arr = lib.futhark_new_i32_2d(fctx, src.ctypes.data, 7, 11)
+    assert arr and lib.futhark_values_raw_i32_2d(fctx, arr)
+    shp = lib.futhark_shape_i32_2d(fctx, arr)
+    assert (shp[0], shp[1]) == (7, 11)
+    back = np.zeros_like(src)
+    lib.futhark_values_i32_2d.argtypes = [vp, vp, vp]
+    assert lib.futhark_values_i32_2d(fctx, arr, back.ctypes.data) == 0 and (back == src).all()
+    lib.futhark_free_i32_2d.argtypes = [vp, vp]
+    lib.futhark_free_i32_2d(fctx, arr)
+    lib.futhark_context_clear_caches.argtypes = [vp]
+    assert lib.futhark_context_clear_caches(fctx) == 0
     lib.futhark_context_free.argtypes = [vp]
     lib.futhark_context_config_free.argtypes = [vp]
     lib.futhark_context_free(fctx)
