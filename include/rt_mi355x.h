@@ -74,6 +74,7 @@ int rt_scene_free(rt_context *ctx, rt_scene *scene);
 int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, int64_t w, const rt_scene *scene);
 int rt_prepared_free(rt_context *ctx, rt_prepared *ps);
 int64_t rt_prepared_num_spheres(const rt_prepared *ps);
+int32_t rt_prepared_height(const rt_prepared *ps);   /* levels of inner nodes on the longest root-to-leaf path */
 /* Canonical `bvh = {L, I}` (bvh.fut:28) copied back from the device for parity checks.
  * L7: n x 7 floats; bmin/bmax: (n-1) x 3; left/right: (n-1) encoded ptr (inner i -> i,
  * leaf i -> -2 - i); parent: (n-1).  Any pointer may be NULL. */

@@ -15,7 +15,7 @@ RT_SYMBOLS = [
     "rt_context_set_option", "rt_context_device_info",
     "rt_scene_rgbbox", "rt_scene_irreg", "rt_scene_floor", "rt_scene_from_spheres", "rt_scene_num_spheres",
     "rt_scene_free",
-    "rt_prepare_scene", "rt_prepared_free", "rt_prepared_num_spheres", "rt_prepared_get_bvh",
+    "rt_prepare_scene", "rt_prepared_free", "rt_prepared_num_spheres", "rt_prepared_height", "rt_prepared_get_bvh",
     "rt_prepared_get_camera",
     "rt_render", "rt_render_part", "rt_render_image", "rt_part_rows", "rt_place_part", "rt_place_parts", "rt_place_parts_strided", "rt_render_stats", "rt_render_trace",
     "rt_render_timed",
@@ -67,6 +67,7 @@ def _load():
         "rt_prepare_scene": (C.c_int, [vp, C.POINTER(vp), i64, i64, vp]),
         "rt_prepared_free": (C.c_int, [vp, vp]),
         "rt_prepared_num_spheres": (i64, [vp]),
+        "rt_prepared_height": (i32, [vp]),
         "rt_prepared_get_bvh": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
         "rt_prepared_get_camera": (C.c_int, [vp, vp, vp]),
         "rt_render": (C.c_int, [vp, vp, i64, i64, vp]),

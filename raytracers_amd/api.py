@@ -163,6 +163,11 @@ class Prepared:
     def num_spheres(self):
         return int(lib.rt_prepared_num_spheres(self._h))
 
+    @property
+    def height(self):
+        """levels of inner nodes on the longest root-to-leaf path of the BVH"""
+        return int(lib.rt_prepared_height(self._h))
+
     def camera(self):
         cam = np.empty(12, dtype=np.float32)
         self.ctx._check(lib.rt_prepared_get_camera(self.ctx._h, self._h, cam.ctypes.data))

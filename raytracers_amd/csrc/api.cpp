@@ -219,8 +219,9 @@ struct Plan {
 // `ntiles`: 8x8 tiles of the launch (grid_div == 0 picks the launch size from it: up to ~1000x1000 a
 // half-size launch keeps the waves better filled -- 5-18 % per frame --, larger frames want every wave).
 int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) {
+  const bool auto_variant = ctx->variant == RT_VARIANT_AUTO;
   pl->variant = ctx->variant;
-  if (pl->variant == RT_VARIANT_AUTO) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
+  if (auto_variant) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
   if (pl->variant == RT_VARIANT_PIXEL) return 0;
   const int ni = static_cast<int>(ps->n - 1), n = static_cast<int>(ps->n);
   // depth-first with one node held in a register: at most one pending sibling per level
@@ -228,19 +229,34 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) 
   int smax = 64;
   for (int cand : {12, 16, 20, 24, 32, 48, 64})
     if (cand >= need) { smax = cand; break; }
-  if (need > 64) return fail(ctx, "BVH deeper than 64 levels: unsupported by the persistent kernel");
+  if (need > 64) {
+    if (auto_variant) { pl->variant = RT_VARIANT_PIXEL; return 0; }
+    return fail(ctx, "BVH deeper than 64 levels: unsupported by the persistent kernels");
+  }
   pl->smax = smax;
   pl->lmax = ctx->lmax;
-  pl->waves = ctx->waves_per_wg;
-  const int total = std::min(ctx->lds_bytes, 160 * 1024) / std::max(1, ctx->wgs_per_cu);
   // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
   pl->capb = 64 * (ps->height + 3);
   pl->capl = 256;
-  const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl) * 4
-                                                       : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
-  int budget = total - scratch - 512;
+  // The per-wave scratch grows with the tree height (equal Morton keys make tall trees): when the
+  // configured workgroup shape does not fit the CU's LDS, fall back to fewer / smaller workgroups
+  // before giving up (AUTO then renders with the pixel kernel, which needs no LDS).
+  const int shapes[][2] = {{ctx->wgs_per_cu, ctx->waves_per_wg}, {1, 8}, {1, 4}};
+  int budget = -1, wgs = ctx->wgs_per_cu;
+  for (const auto &sh : shapes) {
+    wgs = std::max(1, sh[0]);
+    pl->waves = sh[1];
+    const int total = std::min(ctx->lds_bytes, 160 * 1024) / wgs;
+    const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl) * 4
+                                                         : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
+    budget = total - scratch - 512;
+    if (budget >= 0) break;
+  }
+  if (budget < 0) {
+    if (auto_variant) { pl->variant = RT_VARIANT_PIXEL; return 0; }
+    return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
+  }
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
-  if (budget < 0) return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
   int ln, ls;
   const int node_bytes = pl->variant == RT_VARIANT_POOLED ? 64 : 32;
   if (ctx->lds_sph_first) {
@@ -255,7 +271,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) 
   pl->lds_bytes = pl->variant == RT_VARIANT_POOLED ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
                                                    : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
   const int div = ctx->grid_div > 0 ? ctx->grid_div : (pl->variant == RT_VARIANT_POOLED && ntiles <= 32768 ? 2 : 1);
-  pl->grid = std::max(1, ctx->num_cu * ctx->wgs_per_cu / div);
+  pl->grid = std::max(1, ctx->num_cu * wgs / div);
   // workgroups go round-robin to the 8 XCDs: keep their number a multiple of 8 so that no XCD carries
   // one more persistent workgroup than the others (grid_div=12 -> 42 workgroups measured +15 %)
   if (pl->grid >= 8) pl->grid -= pl->grid % 8;
@@ -656,6 +672,7 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
 }
 
 extern "C" int64_t rt_prepared_num_spheres(const rt_prepared *ps) { return ps ? ps->n : 0; }
+extern "C" int32_t rt_prepared_height(const rt_prepared *ps) { return ps ? ps->height : 0; }
 
 extern "C" int rt_prepared_get_bvh(rt_context *ctx, const rt_prepared *ps, float *L7, float *bmin, float *bmax,
                                    int32_t *left, int32_t *right, int32_t *parent) {

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: random scenes / cameras / image sizes, GPU (both BVH builders, all
+kernel families) against the CPU oracle, bit-exact.  usage: fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+import raytracers_amd as R
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = R.Context()
+t_end = time.time() + budget
+cases = fails = 0
+while time.time() < t_end:
+    seed = seed0 + cases
+    rng = np.random.default_rng(seed)
+    n = int(np.exp(rng.uniform(np.log(2), np.log(20000))))
+    kind = rng.choice(["uniform", "clustered", "grid", "line", "dupes", "shell"])
+    s = np.zeros((n, 7), np.float32)
+    ext = float(rng.choice([5.0, 40.0, 300.0, 3000.0]))
+    if kind == "uniform":
+        s[:, 0:3] = rng.uniform(-ext, ext, (n, 3))
+    elif kind == "clustered":
+        c = rng.uniform(-ext, ext, (max(1, n // 50), 3))
+        s[:, 0:3] = c[rng.integers(0, len(c), n)] + rng.normal(0, ext / 40, (n, 3))
+    elif kind == "grid":
+        k = max(1, int(round(n ** (1 / 3))))
+        g = np.stack(np.meshgrid(*[np.arange(k)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+        s[:len(g), 0:3] = (g - k / 2) * (2 * ext / k)
+        s[len(g):, 0:3] = rng.uniform(-ext, ext, (n - len(g), 3))
+    elif kind == "line":
+        s[:, int(rng.integers(0, 3))] = np.linspace(-ext, ext, n)
+    elif kind == "dupes":
+        base = rng.uniform(-ext, ext, (max(1, n // 7), 3))
+        s[:, 0:3] = base[rng.integers(0, len(base), n)]
+    else:
+        v = rng.normal(0, 1, (n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True) + 1e-9
+        s[:, 0:3] = v * ext
+    s[:, 3:6] = rng.uniform(0.1, 1.0, (n, 3))
+    s[:, 6] = rng.uniform(0.02, 0.2) * ext * rng.uniform(0.2, 1.0, n) if rng.random() < 0.7 else ext * 0.05
+    s = s.astype(np.float32)
+    lf = tuple(float(x) for x in rng.uniform(-2 * ext, 2 * ext, 3))
+    la = tuple(float(x) for x in rng.uniform(-ext / 4, ext / 4, 3))
+    fov = float(rng.uniform(20, 100))
+    h, w = int(rng.integers(1, 160)), int(rng.integers(1, 160))
+    md = int(rng.choice([50, 50, 50, 1, 3, 7]))
+    orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
+    want_bvh = orc.arrays()
+    ref, _ = orc.render(h, w, max_depth=md, threads=min(16, os.cpu_count() or 1))
+    ok = True
+    for gpu_build in (1, 0):
+        ctx.set_option("gpu_build", gpu_build)
+        ps = R.prepare_scene(h, w, ctx.scene_from_spheres(s, lf, la, fov))
+        got = ps.bvh_arrays()
+        for k in ("left", "right", "parent"):
+            ok &= bool((got[k] == want_bvh[k]).all())
+        for k in ("L", "bmin", "bmax"):
+            ok &= got[k].tobytes() == want_bvh[k].tobytes()
+        for variant in ((3, 1, 2) if gpu_build else (3,)):
+            ctx.set_variant(variant)
+            px = R.render(h, w, ps, max_depth=md)
+            px2 = R.render(h, w, ps, max_depth=md)      # second frame: adaptive tile order / deep tiles
+            ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
+    cases += 1
+    if not ok:
+        fails += 1
+        print(f"MISMATCH seed {seed}: n={n} kind={kind} ext={ext} {w}x{h} max_depth={md}", flush=True)
+ctx.set_option("gpu_build", 1)
+print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1})", flush=True)
+sys.exit(1 if fails else 0)
