@@ -16,7 +16,7 @@ cases = fails = 0
 while time.time() < t_end:
     seed = seed0 + cases
     rng = np.random.default_rng(seed)
-    n = int(np.exp(rng.uniform(np.log(2), np.log(20000))))
+    n = int(np.exp(rng.uniform(np.log(2), np.log(60000 if rng.random() < 0.1 else 20000))))
     kind = rng.choice(["uniform", "clustered", "grid", "line", "dupes", "shell"])
     s = np.zeros((n, 7), np.float32)
     ext = float(rng.choice([5.0, 40.0, 300.0, 3000.0]))
@@ -50,6 +50,13 @@ while time.time() < t_end:
     want_bvh = orc.arrays()
     ref, _ = orc.render(h, w, max_depth=md, threads=min(16, os.cpu_count() or 1))
     ok = True
+    # random launch knobs (must never change pixels)
+    knobs = dict(grid_div=int(rng.choice([0, 1, 2, 4, 8, 16])), thr_shade=int(rng.choice([1, 8, 24, 48, 64])),
+                 deep_class=int(rng.integers(0, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
+                 lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([4, 8, 16])),
+                 wgs_per_cu=int(rng.choice([1, 2, 4])))
+    for k, v in knobs.items():
+        ctx.set_option(k, v)
     for gpu_build in (1, 0):
         ctx.set_option("gpu_build", gpu_build)
         ps = R.prepare_scene(h, w, ctx.scene_from_spheres(s, lf, la, fov))
@@ -63,10 +70,26 @@ while time.time() < t_end:
             px = R.render(h, w, ps, max_depth=md)
             px2 = R.render(h, w, ps, max_depth=md)      # second frame: adaptive tile order / deep tiles
             ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
+    # the row-tile partition: every part rendered on its own, assembled in one launch
+    ctx.set_option("gpu_build", 1)
+    ctx.set_variant(0)
+    nparts = int(rng.integers(1, 9))
+    pad = max(R.part_rows(h, p, nparts) for p in range(nparts))
+    if pad > 0:
+        import torch
+        stacked = torch.full((nparts, pad, w), -3, dtype=torch.int32, device="cuda")
+        image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for p in range(nparts):
+            if R.part_rows(h, p, nparts):
+                R.render_into(stacked[p].data_ptr(), h, w, ps, max_depth=md, part=p, nparts=nparts)
+        R.place_parts(ctx, h, w, nparts, pad, stacked.data_ptr(), image.data_ptr())
+        ctx.sync()
+        ok &= int((image.cpu().numpy() != ref).sum()) == 0
     cases += 1
     if not ok:
         fails += 1
-        print(f"MISMATCH seed {seed}: n={n} kind={kind} ext={ext} {w}x{h} max_depth={md}", flush=True)
+        print(f"MISMATCH seed {seed}: n={n} kind={kind} ext={ext} {w}x{h} max_depth={md} knobs={knobs} nparts={nparts}", flush=True)
 ctx.set_option("gpu_build", 1)
 print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1})", flush=True)
 sys.exit(1 if fails else 0)
