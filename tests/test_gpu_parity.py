@@ -245,6 +245,21 @@ def test_tall_trees(R, ctx, dupes, want_height):
     ctx.set_variant(0)
 
 
+def test_many_views_of_one_prepared_scene(R, ctx):
+    """More views (size x camera) of one prepared scene than its tile-order cache holds (8): the
+    oldest records are evicted and re-recorded, every frame stays bit-exact."""
+    ps = R.prepare_scene(64, 64, ctx.scene("rgbbox"))
+    orc = _oracle("rgbbox")
+    sizes = [(40 + 7 * i, 52 + 5 * i) for i in range(11)]
+    refs = {}
+    for rnd in range(3):
+        for h, w in sizes:
+            if (h, w) not in refs:
+                refs[(h, w)] = orc.render(h, w)[0]
+            px = R.render_image(ps, w, h, orc.camera_floats(h, w))
+            assert int((px != refs[(h, w)]).sum()) == 0, (rnd, h, w)
+
+
 def test_random_parity_campaign():
     """tools/fuzz_parity.py: a few seconds of random scenes / cameras / sizes / bounce limits, both
     BVH builders and all kernel families against the oracle (a 200 s run covered 29 337 cases)."""
