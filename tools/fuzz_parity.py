@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: random scenes / cameras / image sizes, GPU (both BVH builders, all
-kernel families) against the CPU oracle, bit-exact.  usage: fuzz_parity.py [seconds] [seed]"""
+kernel families) against the CPU oracle, bit-exact.
+usage: fuzz_parity.py [seconds] [seed] [max image side = 160] [max spheres = 20000]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,13 +11,15 @@ import raytracers_amd as R
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 160
+max_n = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
 ctx = R.Context()
 t_end = time.time() + budget
 cases = fails = 0
 while time.time() < t_end:
     seed = seed0 + cases
     rng = np.random.default_rng(seed)
-    n = int(np.exp(rng.uniform(np.log(2), np.log(60000 if rng.random() < 0.1 else 20000))))
+    n = int(np.exp(rng.uniform(np.log(2), np.log(3 * max_n if rng.random() < 0.1 else max_n))))
     kind = rng.choice(["uniform", "clustered", "grid", "line", "dupes", "shell"])
     s = np.zeros((n, 7), np.float32)
     ext = float(rng.choice([5.0, 40.0, 300.0, 3000.0]))
@@ -44,7 +47,7 @@ while time.time() < t_end:
     lf = tuple(float(x) for x in rng.uniform(-2 * ext, 2 * ext, 3))
     la = tuple(float(x) for x in rng.uniform(-ext / 4, ext / 4, 3))
     fov = float(rng.uniform(20, 100))
-    h, w = int(rng.integers(1, 160)), int(rng.integers(1, 160))
+    h, w = int(rng.integers(1, max_side)), int(rng.integers(1, max_side))
     md = int(rng.choice([50, 50, 50, 1, 3, 7]))
     orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
     want_bvh = orc.arrays()
