@@ -11,27 +11,36 @@ frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total wor
 the framebuffers of a step are gathered to rank 0 over RCCL inside the timed region (ONE
 gather per step: a rank's rows of both frames travel in one send buffer).
 
-Steps are independent frames, so up to --frames-in-flight of them (default 32) are enqueued
-on separate HIP streams, each with its own context and framebuffers: a 1000x1000 frame ends
-with a long tail in which a handful of 50-bounce pixels keep a few waves busy (the frame's
-latency floor), and the next frames' bulk work fills the otherwise idle machine.  All K
-steps complete inside the barrier/synchronize bracket.  The line also reports the strictly
-serial figures (one frame at a time, `serial`), measured right after the timed region.
+Steps are independent frames, so up to --frames-in-flight of them (never more than K) are
+enqueued on separate HIP streams, each with its own context and framebuffers.  All K steps
+complete inside the barrier/synchronize bracket.  `value` is that overlapped throughput; the
+reference's own protocol -- one render + sync at a time (futhark/main.c:107-124) -- is reported
+next to it as `serial_value` / `serial_ms_per_frame`, and the >= 10x-MI100 target check
+(`targets`) is quoted on the serial figures.
+
+Every timed launch is VERIFIED: the framebuffers are poisoned before the timed region and,
+after its closing fence, the images of every lane are checksummed on the device
+(c = c * 31 + pixel) and compared with the oracle's checksums.  A mismatch fails
+the run; the line carries "verified": true.
 
 value = rays of all K steps / wall time (max over ranks), in Mray/s; a ray = one objs_hit
 call (futhark/ray.fut:130).  Ray and box/sphere-test counts come from an instrumented launch
 and are cross-checked against the oracle-derived constants below.
 
-The JSON line also carries
-  roofline      for the dominant kernel (pooled_kernel): ALGORITHMIC bytes (32 B per box test +
-                16 B per sphere test + 4 B per pixel) of the timed region's launches /
-                its wall time, against the 8 TB/s HBM3E peak; per_launch = the dominant launch's
-                bytes / its mean duration measured with events on the launch stream inside the timed
-                region (stretched by the other frames in flight); valu = the VALU-issue fraction;
-  cpu_baseline  the CPU oracle (a port of the reference's Futhark program, OpenMP over rows)
-                timed on this box's host cores on a bounded sample of the same workload.
+roofline: the kernel's binding resource is VALU issue, not HBM (the scenes are LDS / L2
+resident: a frame moves ~10 MB to and from HBM).  `achieved` = VALU wave-instructions per
+second over the timed region (SQ_INSTS_VALU per launch from the committed PMC passes,
+profiles/pmc.json, which carries the hash of the kernel sources it was measured on -- a stale
+file is refused), `peak` = the rate tools/issue_peak.hip measured on this GPU model for
+independent v_add_f32 / v_mul_f32 / v_fma_f32 streams (profiles/issue_peak.json); `mix` prices
+the kernel's own instruction mix with the per-class costs of the same microbenchmark (selects,
+min/max, compares and integer address arithmetic issue at about half the v_add rate).  The
+SURVEY 8d algorithmic-bytes figure is kept under `alg_bytes` (against the LDS pipe that actually
+serves those bytes, and against the 8 TB/s HBM peak for reference) together with the measured HBM
+`traffic`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -44,13 +53,12 @@ sys.path.insert(0, ROOT)
 
 # The frames in flight live on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES
 # hardware queues (default 4, and torch / RCCL take some), and streams that share a queue
-# largely serialise.  Measured on one MI355X (tools/rank_share_probe.py): 8 queues
-# 0.69 ms/step, 12-16 queues 0.54-0.60 and bimodal, 20 queues with 32 lanes 0.53 and steady;
-# with MORE than ~20 queues actually busy (24+ queues and 24+ lanes) the hardware scheduler
-# oversubscribes and a step takes 0.7-1.2 ms.  Must be set before the HIP runtime initialises.
+# largely serialise.  With MORE than ~20 queues actually busy the hardware scheduler
+# oversubscribes.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+NUM_SIMD = 256 * 4
 
 # (rays, box tests, sphere tests) per frame, from the CPU oracle (tests/test_oracle_golden.py
 # pins the oracle to the reference's golden images; SURVEY.md 8d lists the same numbers).
@@ -58,7 +66,18 @@ FRAME_WORK = {
     ("rgbbox", 1000, 1000): (4022099, 117685724, 25443619),
     ("irreg", 1000, 1000): (1728608, 50741777, 9664717),
     ("irreg", 4000, 4000): (27663974, 812246528, 154642404),
+    ("big", 2000, 2000): (6982472, 324712209, 51736177),
 }
+# c = c * 31 + pixel over the row-major packed pixels (u32 wrap): the CPU oracle's images
+# (tests/test_oracle_golden.py::test_checksums_of_the_bench_frames recomputes the 1000x1000 ones)
+FRAME_CHECKSUM = {
+    ("rgbbox", 1000, 1000): 0xfc0f53a6,
+    ("irreg", 1000, 1000): 0xe3b3857c,
+    ("irreg", 4000, 4000): 0xdb269d43,
+    ("big", 2000, 2000): 0x3a198726,
+}
+# README.md:50 (Futhark on an MI100): render ms at 1000x1000; north_star wants >= 10x
+MI100_RENDER_MS = {"rgbbox": 14.0, "irreg": 8.0}
 
 WORKLOADS = {
     "rgbbox+irreg-1000": [("rgbbox", 1000, 1000), ("irreg", 1000, 1000)],
@@ -67,6 +86,8 @@ WORKLOADS = {
     "irreg-4000": [("irreg", 4000, 4000)],
     "big-2000": [("big", 2000, 2000)],
 }
+KERNEL_SOURCES = ["raytracers_amd/csrc/render_kernels.hip", "raytracers_amd/csrc/lane_core.h",
+                  "raytracers_amd/csrc/rt_device.hpp"]
 
 
 def log(*a):
@@ -75,6 +96,15 @@ def log(*a):
 
 def bytes_alg(box, sph, h, w):
     return 32 * box + 16 * sph + 4 * h * w
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/pmc.json records the hash it was measured on"""
+    m = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            m.update(f.read())
+    return m.hexdigest()
 
 
 def effective_cpus():
@@ -131,10 +161,77 @@ def cpu_baseline(frames, budget_s=12.0):
             rdt = time.perf_counter() - t1
             out["rust_algorithm"] = {"value": rrays / rdt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
                                      "sample": f"{rreps} frames of each scene, {rdt:.1f} s",
-                                     "note": "C restatement of rust/src/lib.rs (median-split BVH, eps 0.001): timing only"}
+                                     "note": "C restatement of rust/src/lib.rs (median-split BVH, eps 0.001): timing only, parity unpinned"}
     except Exception as e:   # the baseline must never take the bench line down
         out["rust_algorithm"] = {"error": str(e)}
     return out
+
+
+class Checksummer:
+    """c = c * 31 + pixel (u32 wrap) of a device image, computed on the device: the polynomial
+    sum(pixel_i * 31^(n-1-i)) in wrapping 64-bit arithmetic, low 32 bits."""
+
+    def __init__(self, device):
+        self.device = device
+        self.w = {}
+
+    def __call__(self, img):
+        import torch
+        n = img.numel()
+        if n not in self.w:
+            pw = np.cumprod(np.concatenate([[1], np.full(n - 1, 31, dtype=np.uint64)]).astype(np.uint64))   # wraps mod 2^64
+            self.w[n] = torch.from_numpy(pw[::-1].copy().view(np.int64)).to(self.device)
+        v = (img.reshape(-1).to(torch.int64) & 0xffffffff) * self.w[n]
+        return int(v.sum().item()) & 0xffffffff
+
+
+def roofline_block(frames, world, variant, grid_div, steps, elapsed, per_scene, work):
+    """VALU-issue roofline (+ LDS, HBM side figures) from profiles/pmc.json and profiles/issue_peak.json."""
+    alg = sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * steps / elapsed / 1e9
+    rf = {"bound": "valu_issue", "kernel": "pooled_kernel (the launches of " + " and ".join(f"{s} {w}x{h}" for s, h, w in frames) + ")",
+          "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": None}
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue_peak.json")) as f:
+            ip = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError) as e:
+        rf["note"] = f"profiles/pmc.json or profiles/issue_peak.json unreadable ({e}): no VALU figure"
+        pmc, ip = None, None
+    if pmc is not None:
+        if pmc.get("source_sha256") != kernel_source_hash():
+            rf["stale_pmc"] = True
+            rf["note"] = ("profiles/pmc.json was measured on other kernel sources (hash mismatch): refused; "
+                          "rerun tools/gpu_round.sh and commit its pmc.json")
+        elif variant in (0, 3):
+            key = f"grid_div={grid_div}"
+            ents = [pmc.get("launches", {}).get(f"{s} {w}x{h}", {}).get(key) for s, h, w in frames]
+            if all(ents):
+                peak = float(ip["valu_peak_G"])
+                insts = sum(e["SQ_INSTS_VALU"] for e in ents)
+                ach = insts * steps / elapsed / 1e9
+                rf.update(achieved=ach, peak=peak, frac=ach / peak, insts_per_step=insts,
+                          peak_source="tools/issue_peak.hip (profiles/issue_peak.json): independent v_add/v_mul/v_fma_f32 streams, "
+                                      ">= 2 waves per SIMD, all 256 CUs")
+                # the kernel's own mix priced with the measured per-class issue costs
+                if all("class_ns" in e for e in ents):
+                    busy_ns = sum(e["class_ns"] for e in ents)          # SIMD-nanoseconds of VALU pipe time per step
+                    rf["mix"] = {"valu_pipe_busy": busy_ns * steps / (elapsed * 1e9 * NUM_SIMD),
+                                 "note": "sum over VALU classes of (PMC instruction count x measured ns per wave-instruction per SIMD) "
+                                         "/ (1024 SIMDs x wall time): the fraction of the chip's VALU pipe time the timed region used"}
+                hb = [e.get("hbm_bytes") for e in ents]
+                if all(hb) and world == 1:
+                    rf["traffic"] = sum(hb)
+                lds = [e.get("SQ_LDS_IDX_ACTIVE") for e in ents]
+                if all(lds):
+                    clk = float(ip.get("clock_GHz", 2.4))
+                    rf["lds"] = {"busy": sum(lds) * steps / (elapsed * 256 * clk * 1e9),
+                                 "note": "SQ_LDS_IDX_ACTIVE cycles per step / (256 CUs x wall cycles): LDS pipe utilisation"}
+    rf["alg_bytes"] = {"achieved": alg, "unit": "GB/s", "frac_of_hbm_peak": alg / HBM_PEAK_GBS, "hbm_peak": HBM_PEAK_GBS,
+                       "note": "SURVEY 8d algorithmic bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) of all launches / wall time. "
+                               "These bytes are served from LDS (node records, ray table) and L2, not from HBM -- see traffic -- so "
+                               "the ratio to the HBM peak is a rate, not a utilisation, and may exceed 1"}
+    return rf
 
 
 def main():
@@ -150,11 +247,12 @@ def main():
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=32, help="independent steps enqueued concurrently (streams)")
+    ap.add_argument("--frames-in-flight", type=int, default=24, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
     ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-extra", action="store_true", help="N > 1: skip the irreg 4000x4000 sub-record")
     args = ap.parse_args()
 
     import torch
@@ -187,38 +285,31 @@ def main():
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
-    # Frames in flight and launch size, from tools/rank_share_probe.py (one rank's share of a step at
-    # world sizes 1..8, measured on one MI355X with 20 hardware queues): 32 lanes are steady at
-    # every world size (8 or 16 lanes are bimodal, e.g. 0.50 / 0.56 ms per step), and as a rank's
-    # share of a frame shrinks it takes that many frames in flight to cover a frame's latency
-    # floor (its longest bounce chain): 505 / 252 / 142 / 87 us per step at 1 / 2 / 4 / 8 ranks.
-    S = max(1, args.frames_in_flight)
-    # With many frames in flight a launch need not fill the machine by itself: an eighth of the
+    # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).
+    S = max(1, min(args.frames_in_flight, args.steps))
+    # With many frames in flight a launch need not fill the machine by itself: a quarter of the
     # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is
     # hidden by the other frames.  One frame at a time keeps the library default.
     opts_pipe = dict(opts)
     if S >= 4 and args.variant in (0, 3):
-        opts_pipe.setdefault("grid_div", 8)
-        # dedicated waves for the deepest tiles shorten ONE frame's tail (-7 %), which overlapped
-        # frames hide anyway; they cost 2-3 % of throughput here
+        opts_pipe.setdefault("grid_div", 4)
+        # dedicated waves for the deepest tiles shorten ONE frame's tail, which overlapped frames
+        # hide anyway; they cost 2-3 % of throughput here
         opts_pipe.setdefault("deep_class", 0)
     # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
 
     class Lane:
         """the renderers of one frame in flight + the step (render all, one gather, assemble)"""
-        def __init__(self, o):
-            self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in frames]
-            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, frames)], device)
-
-    def make_lane(o):
-        return Lane(o)
+        def __init__(self, o, fr=frames):
+            self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in fr]
+            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device)
 
     lanes = []
     for st in streams:
         with torch.cuda.stream(st):
-            lanes.append(make_lane(opts_pipe))
-    serial_lane = make_lane(opts) if (S > 1 and not args.no_serial_extra) else None   # on the default stream
+            lanes.append(Lane(opts_pipe))
+    serial_lane = Lane(opts) if (S > 1 and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
     renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, lanes[0].prs)]
 
@@ -246,6 +337,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def poison(which):
+        """overwrite the framebuffers so that only the timed launches can make them right"""
+        for ln in which:
+            for img in (ln.step.images or []):
+                img.fill_(0x5a5a5a5a)
+            if not ln.step.direct:
+                ln.step.send.fill_(0x5a5a5a5a)
+
+    cks = Checksummer(device)
+
+    def verify(which, fr, what):
+        """rank 0: every lane's images against the oracle's checksums"""
+        bad = []
+        n = 0
+        if rank == 0:
+            for li, ln in enumerate(which):
+                for (scene, h, w), img in zip(fr, ln.step.images):
+                    want = FRAME_CHECKSUM.get((scene, h, w))
+                    if want is None:
+                        continue
+                    got = cks(img)
+                    n += 1
+                    if got != want:
+                        bad.append(f"{what} lane {li} {scene} {w}x{h}: checksum {got:08x}, oracle {want:08x}")
+        if bad:
+            raise SystemExit("VERIFICATION FAILED (pixels differ from the oracle's):\n  " + "\n  ".join(bad))
+        return n
+
     def timed(nsteps, nlanes):
         every = max(1, args.event_every)
         ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
@@ -272,12 +391,54 @@ def main():
         step(k)
     for k in range(args.warmup):
         step(k)
+    torch.cuda.synchronize()
+    poison(lanes)
     elapsed, kern_ms = timed(args.steps, S)
+    n_verified = verify(lanes[:min(S, args.steps)], frames, "timed region,")
     serial = None
     if serial_lane is not None:
         for k in range(3):
             step(k, None, 0)
-        serial = timed(max(10, args.steps // 2), 0)
+        torch.cuda.synchronize()
+        poison([serial_lane])
+        nser = max(10, args.steps // 2)
+        serial = timed(nser, 0)
+        n_verified += verify([serial_lane], frames, "serial region,")
+
+    # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
+    scale_extra = None
+    if world > 1 and not args.no_scale_extra and args.workload == "rgbbox+irreg-1000":
+        fr4 = [("irreg", 4000, 4000)]
+        big_lane = Lane(opts, fr4)
+        for _ in range(2):
+            big_lane.step.render()
+        torch.cuda.synchronize()
+        poison([big_lane])
+        n4 = 6
+        evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n4)]
+        evg = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n4)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(n4):
+            big_lane.step.render([evr[k]], gather_events=evg[k])
+            torch.cuda.synchronize()          # the reference's protocol: render, then sync (main.c:113-117)
+        fence()
+        dt4 = time.perf_counter() - t0
+        t = torch.tensor([dt4, float(np.mean([a.elapsed_time(b) for a, b in evr]))], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        n_verified += verify([big_lane], fr4, "irreg 4000x4000,")
+        if rank == 0:
+            r4 = FRAME_WORK[("irreg", 4000, 4000)][0]
+            ms = float(tmax[0].item()) / n4 * 1e3
+            scale_extra = {"workload": "irreg 4000x4000, one frame at a time (render + gather + sync per frame)",
+                           "ms_per_frame": ms, "Mray_s": r4 / ms / 1e3,
+                           "render_us_per_rank": {"slowest": float(tmax[1].item()) * 1e3, "fastest": float(tmin[1].item()) * 1e3},
+                           "gather_and_assemble_us_rank0": float(np.mean([a.elapsed_time(b) for a, b in evg])) * 1e3,
+                           "frames": n4, "verified": True}
+        del big_lane
 
     if rank == 0:
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
@@ -288,80 +449,53 @@ def main():
             ba = bytes_alg(b, s, h, w) / world        # this rank's share of the frame (cyclic tiles)
             per_scene[f"{scene}_{w}x{h}"] = {
                 "rays": r, "kernel_ms": kern_ms[i], "Mray_s_kernel": r / world / (kern_ms[i] * 1e-3) / 1e6,
-                "alg_bytes_per_launch": ba, "alg_GBs": ba / (kern_ms[i] * 1e-3) / 1e9}
-        # the dominant launch = the one that carries the most algorithmic work of the step
-        dom = max(range(len(renderers)), key=lambda i: per_scene[f"{frames[i][0]}_{frames[i][2]}x{frames[i][1]}"]["alg_bytes_per_launch"])
-        dscene, dh, dw = frames[dom]
-        dkey = f"{dscene}_{dw}x{dh}"
-        achieved = per_scene[dkey]["alg_GBs"]
+                "alg_bytes_per_launch": ba}
+        inflight = sum(kern_ms) * args.steps / (elapsed * 1e3)
         out = {
             "metric": "Mray/s (primary+secondary) on rgbbox & irreg 1000x1000" if args.workload == "rgbbox+irreg-1000"
                       else f"Mray/s (primary+secondary) on {args.workload}",
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
+            "verified": True, "verified_images": n_verified,
+            "value_protocol": f"overlapped throughput: {S} independent frames in flight on {S} HIP streams, all {args.steps} steps inside "
+                              "the timed bracket; the reference's protocol (one render + sync at a time) is serial_value",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
                        "options": opts_pipe, "frames_in_flight": S,
                        "partition": f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per step"
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
-            "roofline": {"bound": "hbm",
-                         "kernel": {0: "pooled_kernel", 1: "pixel_kernel", 2: "persistent_kernel", 3: "pooled_kernel"}[args.variant]
-                                   + " (the launches of " + " and ".join(f"{s} {w}x{h}" for s, h, w in frames) + ")",
-                         # launches of up to frames_in_flight frames share the GPU, so the kernel's rate is
-                         # what all of them together get through per second
-                         "achieved": sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * args.steps / elapsed / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "per_launch": {"kernel": f"{dscene} {dw}x{dh}", "alg_bytes": per_scene[dkey]["alg_bytes_per_launch"],
-                                        "avg_launch_ms": kern_ms[dom], "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                        "avg_launches_in_flight": sum(kern_ms) * args.steps / (elapsed * 1e3),
-                                        "note": "HIP events around each launch on its own stream inside the timed region; "
-                                                "the launches in flight stretch one another"},
-                         "note": "achieved = ALGORITHMIC bytes (32 B/box test + 16 B/sphere test + 4 B/pixel) of all launches "
-                                 "in the timed region / its wall time; per_launch = the dominant launch's bytes / its mean "
-                                 "event-bracketed duration while the other frames in flight share the GPU; "
-                                 "frac_one_frame_at_a_time = the same launch alone on the GPU.  The scene is LDS/L2 "
-                                 "resident: measured HBM traffic (traffic, bytes per step from the PMC passes) is a few MB, so "
-                                 "the nominal HBM roofline can be exceeded; what binds is VALU issue (valu)"},
             "per_scene": per_scene,
+            "pipeline": {"avg_launches_in_flight": inflight,
+                         "fill_drain_note": "the timed bracket starts and ends with an idle GPU: with K steps of t ms and a launch "
+                                            "latency of L ms (per_scene kernel_ms) the bracket is about K t + L, so short runs "
+                                            "under-report the steady state by L / (K t)"},
             "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
-                                  "note": "README.md:50 render times / oracle ray counts; different hardware"},
+                                  "note": "README.md:50 render times / oracle ray counts; different hardware; compare with serial_*"},
         }
-        # measured HBM traffic of that launch: PMC counters cannot be collected inside this run; the
-        # figure comes from the committed PMC passes (profiles/traffic.json, tools/gpu_pmc.sh)
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                trj = json.load(f)
-            trs = [trj.get(f"pooled_kernel {s} {w}x{h}", {}).get("hbm_bytes") for s, h, w in frames]
-            if all(trs) and args.variant in (0, 3) and world == 1:
-                out["roofline"]["traffic"] = sum(trs)   # HBM bytes of one step's launches
-            # what actually bounds this kernel: VALU issue.  wave-instructions of all launches of a
-            # step (PMC SQ_INSTS_VALU at the bench's launch size) / step time, against one VALU
-            # wave64 instruction per 4 clocks per SIMD at the 2.4 GHz peak clock
-            key = "valu_insts_bench_launch" if opts_pipe.get("grid_div", 1) == 8 else "valu_insts"
-            vi = [trj.get(f"pooled_kernel {s} {w}x{h}", {}).get(key) for s, h, w in frames]
-            if all(vi) and args.variant in (0, 3) and world == 1:
-                peak = 256 * 4 * 2.4e9 / 4
-                ach = sum(vi) * args.steps / elapsed
-                out["roofline"]["valu"] = {"bound": "valu issue", "insts_per_step": sum(vi), "achieved": ach / 1e9,
-                                           "peak": peak / 1e9, "unit": "G wave-instr/s", "frac": ach / peak,
-                                           "note": "SQ_INSTS_VALU per launch from the committed PMC pass (profiles/"
-                                                   "traffic.json) x launches per step / measured step time"}
-        except (OSError, ValueError, KeyError):
-            pass
+        out["roofline"] = roofline_block(frames, world, args.variant, opts_pipe.get("grid_div", 0), args.steps, elapsed, per_scene, work)
+        out["roofline"]["per_launch"] = {
+            "kernel_ms": {k: per_scene[k]["kernel_ms"] for k in per_scene}, "avg_launches_in_flight": inflight,
+            "note": "HIP events around each launch on its own stream inside the timed region; launches in flight stretch one another"}
         if serial is not None:
             sdt, skms = serial
-            out["roofline"]["frac_one_frame_at_a_time"] = (bytes_alg(work[frames[dom]][1], work[frames[dom]][2], dh, dw) / world
-                                                          / (skms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-            nser = max(10, args.steps // 2)
+            out["serial_value"] = rays_step * nser / sdt / 1e6
+            out["serial_ms_per_frame"] = {f"{sc}_{w}x{h}": skms[i] for i, (sc, h, w) in enumerate(frames)}
             out["serial"] = {
-                "note": "one frame at a time on one stream (no frames overlapped), measured after the timed region",
-                "value": rays_step * nser / sdt / 1e6, "ms_per_step": sdt / nser * 1e3,
-                "kernel_ms": {f"{sc}_{w}x{h}": skms[i] for i, (sc, h, w) in enumerate(frames)},
-                "roofline_frac": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
-                                  / (skms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS for i, (sc, h, w) in enumerate(frames)}}
+                "note": "the reference's protocol: one frame at a time on one stream (futhark/main.c:107-124), library-default "
+                        "knobs, measured right after the timed region; kernel_ms = HIP events around each launch",
+                "value": out["serial_value"], "ms_per_step": sdt / nser * 1e3, "kernel_ms": out["serial_ms_per_frame"],
+                "alg_bytes_GBs": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
+                                  / (skms[i] * 1e-3) / 1e9 for i, (sc, h, w) in enumerate(frames)}}
+            tg = {}
+            for i, (sc, h, w) in enumerate(frames):
+                if sc in MI100_RENDER_MS and (h, w) == (1000, 1000) and world == 1:
+                    tg[sc] = {"mi100_ms": MI100_RENDER_MS[sc], "ms": skms[i], "speedup": MI100_RENDER_MS[sc] / skms[i],
+                              "target_10x_met": MI100_RENDER_MS[sc] / skms[i] >= 10.0}
+            if tg:
+                out["targets"] = {"note": ">= 10x the published MI100 Futhark render times (README.md:50), one frame at a time", **tg}
+        if scale_extra is not None:
+            out["irreg_4000"] = scale_extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         result_line = json.dumps(out)

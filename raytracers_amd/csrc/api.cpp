@@ -31,9 +31,9 @@ struct rt_context {
   std::string name;
   // configuration
   int variant = RT_VARIANT_AUTO;
-  int waves_per_wg = 8;     // persistent family: waves per workgroup (4, 8, 16)
-  int wgs_per_cu = 2;       // persistent workgroups per CU
-  int thr_shade = 24;       // phase vote: lanes wanting the shade phase that trigger it
+  int waves_per_wg = 0;     // persistent families: waves per workgroup (4, 8, 12, 16); 0 = chosen per scene (make_plan)
+  int wgs_per_cu = 1;       // persistent workgroups per CU (used with a configured waves_per_wg)
+  int thr_shade = 40;       // lanes with a finished fold / a vacant slot that trigger the shade phase
   int thr_leaf = 24;        // phase vote: lanes holding deferred leaves that trigger the sphere phase
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
@@ -218,11 +218,13 @@ struct Plan {
 // Decide the launch shape of the persistent family for one prepared scene.
 // `ntiles`: 8x8 tiles of the launch (grid_div == 0 picks the launch size from it: up to ~1000x1000 a
 // half-size launch keeps the waves better filled -- 5-18 % per frame --, larger frames want every wave).
-int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) {
+// `force_waves` != 0: only workgroups of that many waves (the instrumented instantiation has 8).
+int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, int force_waves = 0) {
   const bool auto_variant = ctx->variant == RT_VARIANT_AUTO;
   pl->variant = ctx->variant;
   if (auto_variant) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
   if (pl->variant == RT_VARIANT_PIXEL) return 0;
+  const bool pooled = pl->variant == RT_VARIANT_POOLED;
   const int ni = static_cast<int>(ps->n - 1), n = static_cast<int>(ps->n);
   // depth-first with one node held in a register: at most one pending sibling per level
   const int need = ps->height + 1;
@@ -237,28 +239,47 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) 
   pl->lmax = ctx->lmax;
   // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
   pl->capb = 64 * (ps->height + 3);
-  pl->capl = 256;
-  // The per-wave scratch grows with the tree height (equal Morton keys make tall trees): when the
-  // configured workgroup shape does not fit the CU's LDS, fall back to fewer / smaller workgroups
-  // before giving up (AUTO then renders with the pixel kernel, which needs no LDS).
-  const int shapes[][2] = {{ctx->wgs_per_cu, ctx->waves_per_wg}, {1, 8}, {1, 4}};
-  int budget = -1, wgs = ctx->wgs_per_cu;
-  for (const auto &sh : shapes) {
-    wgs = std::max(1, sh[0]);
-    pl->waves = sh[1];
-    const int total = std::min(ctx->lds_bytes, 160 * 1024) / wgs;
-    const int scratch = pl->variant == RT_VARIANT_POOLED ? pl->waves * (196 + pl->capb + pl->capl) * 4
-                                                         : pl->waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
-    budget = total - scratch - 512;
-    if (budget >= 0) break;
+  pl->capl = 192;
+  // Workgroup shape {workgroups per CU, waves per workgroup}.  The per-wave scratch grows with the
+  // tree height (equal Morton keys make tall trees) and every workgroup stages its own copy of the
+  // scene prefix, so: a configured shape is tried first; otherwise the shape with the most waves per
+  // CU in which the WHOLE scene still fits in LDS, and for scenes that cannot fit the shape list in
+  // the order measured best for them.  When nothing fits AUTO renders with the pixel kernel (no LDS).
+  struct Shape { int wgs, waves; };
+  std::vector<Shape> shapes;
+  if (force_waves) {
+    shapes = {{std::max(1, ctx->wgs_per_cu), force_waves}, {1, force_waves}};
+  } else {
+    if (ctx->waves_per_wg > 0) shapes.push_back({std::max(1, ctx->wgs_per_cu), ctx->waves_per_wg});
+    if (pooled) for (const Shape &sh : {Shape{1, 16}, Shape{1, 12}, Shape{1, 8}, Shape{1, 4}}) shapes.push_back(sh);
+    else for (const Shape &sh : {Shape{2, 8}, Shape{1, 8}, Shape{1, 4}}) shapes.push_back(sh);
   }
-  if (budget < 0) {
-    if (auto_variant) { pl->variant = RT_VARIANT_PIXEL; return 0; }
+  const int node_bytes = pooled ? 64 : 32;
+  const int64_t scene_bytes = static_cast<int64_t>(ni) * node_bytes + static_cast<int64_t>(n) * 16;
+  auto budget_of = [&](const Shape &sh) {
+    const int total = std::min(ctx->lds_bytes, 160 * 1024) / sh.wgs;
+    const int scratch = pooled ? sh.waves * (rtk::kPooledWaveFixedDw + pl->capb + pl->capl) * 4
+                               : sh.waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
+    return total - scratch - 512;
+  };
+  int pick = -1;
+  const bool configured = !force_waves && ctx->waves_per_wg > 0;
+  if (configured && budget_of(shapes[0]) >= 0) pick = 0;
+  if (pick < 0)
+    for (size_t i = 0; i < shapes.size() && pick < 0; ++i)
+      if (budget_of(shapes[i]) >= scene_bytes) pick = static_cast<int>(i);
+  if (pick < 0)
+    for (size_t i = 0; i < shapes.size() && pick < 0; ++i)
+      if (budget_of(shapes[i]) >= 0) pick = static_cast<int>(i);
+  if (pick < 0) {
+    if (auto_variant && !force_waves) { pl->variant = RT_VARIANT_PIXEL; return 0; }
     return fail(ctx, "LDS budget too small for the per-wave traversal scratch");
   }
+  const int wgs = shapes[static_cast<size_t>(pick)].wgs;
+  pl->waves = shapes[static_cast<size_t>(pick)].waves;
+  int budget = budget_of(shapes[static_cast<size_t>(pick)]);
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   int ln, ls;
-  const int node_bytes = pl->variant == RT_VARIANT_POOLED ? 64 : 32;
   if (ctx->lds_sph_first) {
     ls = std::min(n, budget / 16);
     ln = std::min(ni, (budget - ls * 16) / node_bytes);
@@ -268,9 +289,12 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles) 
   }
   pl->lds_nodes = ln;
   pl->lds_sph = ls;
-  pl->lds_bytes = pl->variant == RT_VARIANT_POOLED ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
-                                                   : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
-  const int div = ctx->grid_div > 0 ? ctx->grid_div : (pl->variant == RT_VARIANT_POOLED && ntiles <= 32768 ? 2 : 1);
+  pl->lds_bytes = pooled ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
+                         : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
+  // launch size: every persistent workgroup, except that a scene which is only partly LDS resident
+  // renders frames up to ~1000x1000 faster with half of them (fuller waves, less L2 traffic in flight)
+  const bool whole_scene = ln == ni && ls == n;
+  const int div = ctx->grid_div > 0 ? ctx->grid_div : (pooled && !whole_scene && ntiles <= 32768 ? 2 : 1);
   pl->grid = std::max(1, ctx->num_cu * wgs / div);
   // workgroups go round-robin to the 8 XCDs: keep their number a multiple of 8 so that no XCD carries
   // one more persistent workgroup than the others (grid_div=12 -> 42 workgroups measured +15 %)
@@ -474,7 +498,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   const std::string k(name);
   const int v = static_cast<int>(value);
   if (k == "waves_per_wg") {
-    if (v != 4 && v != 8 && v != 16) return fail(ctx, "waves_per_wg must be 4, 8 or 16");
+    if (v != 0 && v != 4 && v != 8 && v != 12 && v != 16) return fail(ctx, "waves_per_wg must be 0 (auto), 4, 8, 12 or 16");
     ctx->waves_per_wg = v;
   } else if (k == "wgs_per_cu") {
     if (v < 1 || v > 8) return fail(ctx, "wgs_per_cu must be 1..8");
@@ -772,11 +796,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   Plan pl{};
   const int saved = ctx->variant;
   ctx->variant = RT_VARIANT_POOLED;
-  int rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8));
+  int rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8), 8);   // the instrumented instantiation is the 512-thread one
   ctx->variant = saved;
   if (rc) return rc;
-  pl.waves = 8;   // the instrumented instantiation is the 512-thread one
-  rc = 0;
   const int nw = pl.grid * pl.waves;
   if (nw > max_waves) return fail(ctx, "trace buffer too small");
   int32_t *tmp = nullptr;

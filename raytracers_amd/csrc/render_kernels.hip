@@ -15,6 +15,8 @@
 // the default correctly rounded fp32 divide/sqrt (parity is bit-exact).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "lane_core.h"
 #include "rt_device.hpp"
 
@@ -121,6 +123,8 @@ __device__ __forceinline__ int sel_mask(unsigned long long m, int a, int b) {
 __device__ __forceinline__ void lds_store(int lds_byte_addr, unsigned v) {
   *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((unsigned)lds_byte_addr) = v;
 }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // wave-uniform value -> SGPR
 
 __device__ __forceinline__ int lane_rank(unsigned long long m) {   // # set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -287,17 +291,28 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // ---------------------------------------------------------------------------------
 // Family 3: pooled work items.
 //
-// A wave owns 64 ray SLOTS (slot i's ray lives in lane i's registers) and two work lists in
-// LDS that all lanes share: a LIFO stack of (slot, inner node) items and a list of
-// (slot, leaf) items.  ANY lane processes ANY item -- it pulls the ray it needs from the
-// owning lane with ds_bpermute -- so a traversal step is one dense wave-wide operation
-// whatever the per-ray traversal lengths are, and one ray's subtree is searched by many
-// lanes at once (the fixed (0, 1e9) box interval makes the box tests of a ray independent
-// of its hits, so any order gives the fold's result).  Children are appended with
-// ballot + mbcnt prefix sums.  Per slot, an outstanding-item counter (LDS atomic add) tells
-// when the fold is complete, and the closest hit is an LDS 64-bit atomic min over
-// (bits(t) << 32 | leaf index): smallest t, ties to the lowest leaf index -- exactly
-// closest_hit's accumulator (ray.fut:78-81).
+// A wave owns 64 ray SLOTS and two work lists in LDS that all lanes share: a LIFO stack of
+// (slot, inner node) items and a list of (slot, leaf) items.  ANY lane processes ANY item, so a
+// traversal step is one dense wave-wide operation whatever the per-ray traversal lengths are,
+// and one ray's subtree is searched by many lanes at once (the fixed (0, 1e9) box interval makes
+// the box tests of a ray independent of its hits, so any order gives the fold's result).
+// Children are appended with ballot + mbcnt prefix sums.  Per slot, a counter of outstanding
+// INNER-node items (LDS atomic add) tells when the box part of the fold is complete; the leaf
+// list is always drained before folds are finished, so `counter == 0` then means the whole fold
+// is.  The closest hit is an LDS 64-bit atomic min over (bits(t) << 32 | leaf index): smallest
+// t, ties to the lowest leaf index -- exactly closest_hit's accumulator (ray.fut:78-81).
+//
+// The LDS pipeline is the resource this kernel saturates (tools/issue_peak.hip: a ds_bpermute
+// costs ~3x a ds_read_b32, a ds_read_b128 of 64-byte records at random indices ~6x a
+// conflict-free one, same-address LDS atomics serialise), so the layout is built around it:
+//   * the staged node records are split into four PLANES of 16-byte quarters (record r's
+//     quarter k at plane k + 16 r): the 16 lanes one ds_read_b128 cycle serves then spread over
+//     16 bank groups instead of the 4 a 64-byte stride gives;
+//   * a slot's ray lives in an LDS ray table (three float4 per slot: {o, a} {1/d} {d}) written
+//     once per ray by the owning lane; an item reads its ray with two ds_read_b128 (neighbouring
+//     items mostly share the slot = broadcast) instead of six or seven ds_bpermute;
+//   * one append per child (box stack, leaf list or a dump dword), and the per-slot counter is
+//     touched only by items whose number of inner children differs from one.
 //
 // Bound on the box stack (H = tree height): each operation pops the <= 64 newest items and
 // pushes their <= 128 children, whose depth exceeds their parents'; remainders of at most
@@ -306,13 +321,8 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // ---------------------------------------------------------------------------------
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
-__device__ __forceinline__ float pull(int lane_byte, float v) {
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
-}
-
-// Work items are one dword: (reference << 8) | (slot * 4).  The low byte is the owning
-// lane's byte address for ds_bpermute and for the per-slot counter; `reference` is an inner
-// node index (box stack) or ~leaf index (leaf list), both < 2^23.
+// Work items are one dword: (reference << 8) | (slot * 4); `reference` is an inner node index
+// (box stack) or ~leaf index (leaf list), both < 2^23.
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
@@ -321,22 +331,25 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int sph_base = 4 * p.lds_nodes;   // 64-byte node records = 4 x float4
-  // per-wave region: key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl]
-  const int per_wave_dw = 128 + 64 + 4 + p.capb + p.capl;
+  const int plane = p.lds_nodes;          // float4 per node plane
+  const int sph_base = 4 * plane;
+  // per-wave region: rays[3][64] float4 | key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl]
+  const int per_wave_dw = kPooledWaveFixedDw + p.capb + p.capl;
   unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
-  unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
-  int *const wcnt = reinterpret_cast<int *>(wbase + 128);
-  unsigned *const wdump = wbase + 192;    // where lanes with nothing to append write
-  unsigned *const wbox = wbase + 196;
+  float4 *const wray = reinterpret_cast<float4 *>(wbase);     // [0..63] {o.xyz, a}  [64..127] {1/d, 0}  [128..191] {d, 0}
+  unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase + 768);
+  int *const wcnt = reinterpret_cast<int *>(wbase + 896);
+  unsigned *const wdump = wbase + 960;    // where lanes with nothing to append write
+  unsigned *const wbox = wbase + 964;
   unsigned *const wleaf = wbox + p.capb;
   const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
   const __amdgpu_buffer_rsrc_t rs_col = make_rsrc(p.col, (unsigned)p.n_sph * 16u);
 
-  for (int i = threadIdx.x; i < 4 * p.lds_nodes; i += THREADS) smem[i] = p.nodes64[i];
+  // stage the node prefix as four planes of quarters, then the sphere prefix
+  for (int i = threadIdx.x; i < 4 * plane; i += THREADS) smem[(i & 3) * plane + (i >> 2)] = p.nodes64[i];
   for (int i = threadIdx.x; i < p.lds_sph; i += THREADS) smem[sph_base + i] = p.sph[i];
-  // Zero the work lists: lanes without an item read a stale entry and compute on it with
+  // Zero the wave's region: lanes without an item read a stale entry and compute on it with
   // their results masked off, so every stale entry must decode to valid indices.
   for (int i = lane; i < per_wave_dw; i += 64) wbase[i] = 0u;
   __syncthreads();
@@ -367,16 +380,18 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // both counters are wave-uniform by construction (ballot popcounts); pin them to SGPRs --
-    // hipcc's divergence analysis otherwise carries them in VGPRs and predicates the phases
-    nbox = __builtin_amdgcn_readfirstlane(nbox);
-    nleaf = __builtin_amdgcn_readfirstlane(nleaf);
+    // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
+    // through uni(): hipcc's divergence analysis otherwise carries them in VGPRs and predicates
+    // the phases)
     if (STATS) {
       tr_maxbox = nbox > tr_maxbox ? nbox : tr_maxbox;
       tr_maxleaf = nleaf > tr_maxleaf ? nleaf : tr_maxleaf;
     }
+    bool drain = false;    // the leaf list must be emptied before folds can be finished
     if (nbox < 64 && nleaf < 64) {
-      // not a full wave of work in either list: look at completed folds / vacant slots
+      // not a full wave of work in either list: look at completed folds / vacant slots.  With
+      // leaf items pending `done` over-estimates (the counter covers inner-node items only): it
+      // then only decides whether to drain the leaf list now.
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
       if (hold && bal(pix >= 0) == 0ull) {   // the deep tile is finished: back to normal service
         hold = false;
@@ -387,134 +402,142 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       // a short box stack means idle lanes in the coming BOX operations: be more eager to start
       // new folds then (thr_shade_low applies while nbox < low_box)
       const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
-      if (ns >= thr || (nbox | nleaf) == 0) {
-        if (ns == 0) break;
-        // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
-        bool root = false;
-        if (STATS) tr_ops[2]++;
-        if (done) {
-          if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
-          const unsigned long long key = wkey[lane];
-          const float best = __uint_as_float((unsigned)(key >> 32));
-          const bool hit = key != kKeyInit;
-          const int bestj = (int)((unsigned)key >> 1);
-          // winner's sphere and colour: both loads are issued before either is used (two
-          // dependent global latencies in a row were ~10 % of a lone wave's bounce); the sphere
-          // comes from the LDS copy when it is staged
-          const int wj = hit ? bestj : 0;
-          float4 c = buf_load16(rs_col, wj * 16), s;
-          if (ALL_LDS) {
-            s = smem[sph_base + wj];
-          } else {
-            s = smem[sph_base + (wj < p.lds_sph ? wj : 0)];
-            if (wj >= p.lds_sph) s = buf_load16(rs_sph, wj * 16);
+      if (ns >= thr || nbox == 0) {
+        if (nleaf > 0) {
+          drain = true;
+        } else {
+          if (ns == 0) break;
+          // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
+          bool root = false;
+          if (STATS) tr_ops[2]++;
+          if (done) {
+            if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
+            const unsigned long long key = wkey[lane];
+            const float best = __uint_as_float((unsigned)(key >> 32));
+            const bool hit = key != kKeyInit;
+            const int bestj = (int)((unsigned)key >> 1);
+            // winner's sphere and colour: both loads are issued before either is used (two
+            // dependent global latencies in a row were ~10 % of a lone wave's bounce); the sphere
+            // comes from the LDS copy when it is staged
+            const int wj = hit ? bestj : 0;
+            float4 c = buf_load16(rs_col, wj * 16), s;
+            if (ALL_LDS) {
+              s = smem[sph_base + wj];
+            } else {
+              s = smem[sph_base + (wj < p.lds_sph ? wj : 0)];
+              if (wj >= p.lds_sph) s = buf_load16(rs_sph, wj * 16);
+            }
+            if (!hit) {
+              s = make_float4(0.f, 0.f, 0.f, 1.f);
+              c = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // the (0.0, t+1) re-intersection returns t = best unless the fold's root was
+            // displaced (near_root) or best+1 rounds to best: only then redo it literally
+            bool have = hit;
+            float t = best;
+            if (hit && !rehit_is_best(best, ((unsigned)key & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
+            int32_t pixel;
+            if (shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
+              root = true;
+            } else {
+              p.out[pix] = pixel;
+              pix = -1;
+              // cost record for the adaptive tile order: the longest bounce chain seen in the tile
+              if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
+            }
           }
-          if (!hit) {
-            s = make_float4(0.f, 0.f, 0.f, 1.f);
-            c = make_float4(0.f, 0.f, 0.f, 0.f);
+          bool want = (pix < 0) & !exhausted & !hold;
+          int slot = -1;
+          unsigned long long m = bal(want);
+          while (m != 0ull) {            // wave-uniform loop
+            if (q_next == q_end) {
+              if (hold) break;           // a deep tile is in flight: no further tickets for now
+              unsigned t = 0;
+              if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
+              t = __builtin_amdgcn_readfirstlane(t);
+              if (t >= (unsigned)p.nchunks) {
+                exhausted = true;
+                if (STATS) tr_exh = clock64();
+                break;
+              }
+              q_next = t * 64u;
+              q_end = q_next + 64u;
+              q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
+              if (p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
+                hold = true;
+                __builtin_amdgcn_s_setprio(3);
+              }
+              const int ty = q_tile / p.tiles_x;                    // once per ticket, scalar
+              q_col0 = (q_tile - ty * p.tiles_x) * 8;
+              q_row0 = ty * 8;
+            }
+            const unsigned avail = q_end - q_next;
+            const unsigned rank = (unsigned)lane_rank(m);
+            const unsigned cnt = (unsigned)__popcll(m);
+            if (want & (rank < avail)) {
+              const int within = (int)((q_next + rank) & 63u);
+              const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
+              if (col < p.w && lrow < p.rows_local) {
+                slot = lrow * p.w + col;
+                ptile = q_tile;
+                // cyclic row tiles with rows_per_tile = 1 << rpt_log2 (division-free global_row)
+                const int k = lrow >> p.rpt_log2;
+                const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+                primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
+                want = false;
+              }
+            }
+            q_next += (cnt < avail) ? cnt : avail;
+            m = bal(want);
           }
-          // the (0.0, t+1) re-intersection returns t = best unless the fold's root was
-          // displaced (near_root) or best+1 rounds to best: only then redo it literally
-          bool have = hit;
-          float t = best;
-          if (hit && !rehit_is_best(best, ((unsigned)key & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
-          int32_t pixel;
-          if (shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
+          if (slot >= 0) {
+            lr = 1.0f; lg = 1.0f; lb = 1.0f;
+            depth = 0;
+            pix = slot;
             root = true;
-          } else {
-            p.out[pix] = pixel;
-            pix = -1;
-            // cost record for the adaptive tile order: the longest bounce chain seen in the tile
-            if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
           }
-        }
-        bool want = (pix < 0) & !exhausted & !hold;
-        int slot = -1;
-        unsigned long long m = bal(want);
-        while (m != 0ull) {            // wave-uniform loop
-          if (q_next == q_end) {
-            if (hold) break;           // a deep tile is in flight: no further tickets for now
-            unsigned t = 0;
-            if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= (unsigned)p.nchunks) {
-              exhausted = true;
-              if (STATS) tr_exh = clock64();
-              break;
-            }
-            q_next = t * 64u;
-            q_end = q_next + 64u;
-            q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
-            if (p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
-              hold = true;
-              __builtin_amdgcn_s_setprio(3);
-            }
-            const int ty = q_tile / p.tiles_x;                    // once per ticket, scalar
-            q_col0 = (q_tile - ty * p.tiles_x) * 8;
-            q_row0 = ty * 8;
+          // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
+          if (root) ray_derive(r);   // one place for both scattered and primary rays
+          const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
+          if (root) {
+            wkey[lane] = kKeyInit;
+            wcnt[lane] = root_hit ? 1 : 0;    // 0: the fold is already complete (a miss), shaded next time
+            wray[lane] = make_float4(r.ox, r.oy, r.oz, r.a);
+            wray[64 + lane] = make_float4(r.ix, r.iy, r.iz, 0.0f);
+            wray[128 + lane] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+            if (STATS) { n_rays++; n_box++; }
           }
-          const unsigned avail = q_end - q_next;
-          const unsigned rank = (unsigned)lane_rank(m);
-          const unsigned cnt = (unsigned)__popcll(m);
-          if (want & (rank < avail)) {
-            const int within = (int)((q_next + rank) & 63u);
-            const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
-            if (col < p.w && lrow < p.rows_local) {
-              slot = lrow * p.w + col;
-              ptile = q_tile;
-              // cyclic row tiles with rows_per_tile = 1 << rpt_log2 (division-free global_row)
-              const int k = lrow >> p.rpt_log2;
-              const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
-              primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
-              want = false;
-            }
+          const unsigned long long m_root = bal(root_hit);
+          if (root_hit) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
+          nbox = uni(nbox + __popcll(m_root));
+          // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
+          // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
+          // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
+          if (p.prio_depth > 0 && !hold) {
+            const bool live = pix >= 0;
+            if (bal(live && depth >= 4 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(3);
+            else if (bal(live && depth >= 2 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(2);
+            else if (bal(live && depth >= p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
           }
-          q_next += (cnt < avail) ? cnt : avail;
-          m = bal(want);
+          continue;
         }
-        if (slot >= 0) {
-          lr = 1.0f; lg = 1.0f; lb = 1.0f;
-          depth = 0;
-          pix = slot;
-          root = true;
-        }
-        // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
-        if (root) ray_derive(r);   // one place for both scattered and primary rays
-        const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
-        if (root) {
-          wkey[lane] = kKeyInit;
-          wcnt[lane] = root_hit ? 1 : 0;    // 0: the fold is already complete (a miss), shaded next time
-          if (STATS) { n_rays++; n_box++; }
-        }
-        const unsigned long long m_root = bal(root_hit);
-        if (root_hit) wbox[nbox + lane_rank(m_root)] = (unsigned)lane << 2;   // (node 0, slot = lane)
-        nbox += __popcll(m_root);
-        // Issue priority follows the deepest bounce chain this wave carries: the frame cannot
-        // end before its longest chain (up to 50 dependent folds) does, and a wave that shares
-        // its SIMD's issue slots evenly with 3 others walks that chain 4x slower.
-        if (p.prio_depth > 0 && !hold) {
-          const bool live = pix >= 0;
-          if (bal(live && depth >= 4 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(3);
-          else if (bal(live && depth >= 2 * p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(2);
-          else if (bal(live && depth >= p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-        }
-        continue;
       }
     }
-    if (nleaf >= 64 || nbox == 0 || (nbox < p.low_box && nleaf >= p.low_leaf)) {
+    if (drain || nleaf >= 64 || nbox == 0 || (nbox < p.low_box && nleaf >= p.low_leaf)) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;
       const unsigned item = wleaf[top < 0 ? 0 : top];
       const bool act = top >= 0;
-      nleaf = nleaf > 64 ? nleaf - 64 : 0;
-      const int sl4 = (int)(item & 0xfcu);
+      nleaf = uni(nleaf > 64 ? nleaf - 64 : 0);
+      const int sl = (int)(item & 0xfcu) >> 2;
       const int j = ~((int)item >> 8);        // stale zero entry -> ~0 = -1: masked below
+      const float4 ra = wray[sl], rd = wray[128 + sl];
+      asm volatile("" ::"v"(rd.w));           // keep both as 16-byte reads (ds_read_b96 is slower)
       Ray q;
-      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
-      q.dx = pull(sl4, r.dx); q.dy = pull(sl4, r.dy); q.dz = pull(sl4, r.dz);
-      q.a = pull(sl4, r.a);
+      q.ox = ra.x; q.oy = ra.y; q.oz = ra.z; q.a = ra.w;
+      q.dx = rd.x; q.dy = rd.y; q.dz = rd.z;
       const int jj = act ? j : 0;
       float4 s;
       if (ALL_LDS) {
@@ -528,33 +551,34 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const float g = sphere_root_flag(q, s.x, s.y, s.z, s.w, &near_root);
       // key = (bits(t), leaf << 1 | near_root): min = smallest t, ties to the lowest leaf
       if (act & (g < kTMax))
-        atomicMin(&wkey[sl4 >> 2],
+        atomicMin(&wkey[sl],
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
-      atomicAdd(&wcnt[sl4 >> 2], act ? -1 : 0);   // unconditional: cheaper than masking the lanes
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
       if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
       const int top = nbox - 1 - lane;
       const unsigned item = wbox[top < 0 ? 0 : top];
-      nbox = nbox > 64 ? nbox - 64 : 0;
+      nbox = uni(nbox > 64 ? nbox - 64 : 0);
       const int sl4 = (int)(item & 0xfcu);
       const int ni = (int)(item >> 8);
+      const float4 ra = wray[sl4 >> 2], ri = wray[64 + (sl4 >> 2)];
       Ray q;
-      q.ox = pull(sl4, r.ox); q.oy = pull(sl4, r.oy); q.oz = pull(sl4, r.oz);
-      q.ix = pull(sl4, r.ix); q.iy = pull(sl4, r.iy); q.iz = pull(sl4, r.iz);
+      q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
+      q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
       float4 q0, q1, q2, q3;
       if (ALL_LDS) {
-        q0 = smem[4 * ni]; q1 = smem[4 * ni + 1]; q2 = smem[4 * ni + 2]; q3 = smem[4 * ni + 3];
+        q0 = smem[ni]; q1 = smem[plane + ni]; q2 = smem[2 * plane + ni]; q3 = smem[3 * plane + ni];
       } else {
-        const int li = ni < p.lds_nodes ? ni : 0;
-        q0 = smem[4 * li]; q1 = smem[4 * li + 1]; q2 = smem[4 * li + 2]; q3 = smem[4 * li + 3];
-        if (ni >= p.lds_nodes) {
+        const int li = ni < plane ? ni : 0;
+        q0 = smem[li]; q1 = smem[plane + li]; q2 = smem[2 * plane + li]; q3 = smem[3 * plane + li];
+        if (ni >= plane) {
           q0 = buf_load16(rs_nodes, ni * 64);
           q1 = buf_load16(rs_nodes, ni * 64 + 16);
           q2 = buf_load16(rs_nodes, ni * 64 + 32);
           q3 = buf_load16(rs_nodes, ni * 64 + 48);
         }
       }
+      asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w));   // 16-byte reads throughout
       const int cl = f2i(q0.w), cr = f2i(q1.w);
       // lane masks straight from the compares; the rest is 64-bit scalar logic
       const unsigned long long m_act = bal(top >= 0);
@@ -565,26 +589,22 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
       const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
       if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
-      // append: left children first, then right children (two independent prefix ranks);
-      // lanes with nothing to append write to the dump slot instead of being masked off
+      // append: left children first, then right children (two independent prefix ranks per list);
+      // ONE store per child: to the box stack, to the leaf list, or to the dump dword
       const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-      const int dump = (int)(size_t)(wdump) ;   // LDS byte address (low 32 bits of the flat address)
+      const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
       const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
-      const int a_inl = sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl));
-      const int a_inr = sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr)));
-      const int a_lfl = sel_mask(m_lfl, dump, b_leaf + 4 * lane_rank(m_lfl));
-      const int a_lfr = sel_mask(m_lfr, dump, b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
-      const unsigned vl = ((unsigned)cl << 8) | (unsigned)sl4, vr = ((unsigned)cr << 8) | (unsigned)sl4;
-      lds_store(a_inl, vl);
-      lds_store(a_inr, vr);
-      lds_store(a_lfl, vl);
-      lds_store(a_lfr, vr);
-      nbox += c_inl + __popcll(m_inr);
-      nleaf += c_lfl + __popcll(m_lfr);
-      // one item consumed, k appended: outstanding += k - 1; lanes without an item add 0
-      const unsigned long long m_l = (m_act & (m_ln | m_hl)) | ~m_act, m_r = m_act & (m_rn | m_hr);
-      const int d0 = sel_mask(m_l, -1, 0);
-      atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_r, d0, d0 + 1));
+      const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+      const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr))),
+                               b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
+      lds_store(a_l, ((unsigned)cl << 8) | (unsigned)sl4);
+      lds_store(a_r, ((unsigned)cr << 8) | (unsigned)sl4);
+      nbox = uni(nbox + c_inl + __popcll(m_inr));
+      nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
+      // outstanding inner-node items of the slot: one consumed, k in {0, 1, 2} appended.  Only items
+      // with k != 1 touch the counter (same-address LDS atomics serialise).
+      const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
+      if (sel_mask(m_two | m_none, 0, 1) != 0) atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_two, -1, 1));
     }
   }
   if (STATS) {
@@ -717,6 +737,27 @@ hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Dynamic LDS above 64 KB is an opt-in per kernel AND per device: remembered per (kernel, device) --
+// a process may hold contexts on several GPUs, from several host threads.
+static hipError_t allow_full_lds(const void *kfn) {
+  constexpr int kMaxDev = 64, kMaxFn = 32;
+  static std::mutex mu;
+  static const void *fns[kMaxFn];
+  static unsigned long long done[kMaxFn];   // bit d: set on device d
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  int slot = -1;
+  for (int i = 0; i < kMaxFn && slot < 0; ++i) {
+    if (fns[i] == kfn) slot = i;
+    else if (fns[i] == nullptr) { fns[i] = kfn; slot = i; }
+  }
+  if (slot >= 0 && dev < kMaxDev && (done[slot] >> dev & 1ull)) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+  if (slot >= 0 && dev < kMaxDev) done[slot] |= 1ull << dev;
+  return hipSuccess;
+}
+
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg) {
   return (size_t)lds_nodes * 32 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (smax + 1 + lmax) * 64 * sizeof(int);
 }
@@ -725,13 +766,7 @@ template <int THREADS, bool STATS>
 static hipError_t launch_persistent_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = persistent_lds_bytes(p.lds_nodes, p.lds_sph, p.smax, p.lmax, THREADS / 64);
   auto kfn = persistent_kernel<THREADS, STATS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
 }
@@ -742,26 +777,21 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
   switch (waves_per_wg) {
   case 4: return launch_persistent_t<256, false>(p, grid, stream);
   case 8: return launch_persistent_t<512, false>(p, grid, stream);
+  case 12: return launch_persistent_t<768, false>(p, grid, stream);
   case 16: return launch_persistent_t<1024, false>(p, grid, stream);
   default: return hipErrorInvalidValue;
   }
 }
 
 size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg) {
-  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (196 + capb + capl) * sizeof(unsigned);
+  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (kPooledWaveFixedDw + capb + capl) * sizeof(unsigned);
 }
 
 template <int THREADS, bool ALL_LDS, bool STATS>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, THREADS / 64);
   auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
 }
@@ -773,6 +803,7 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   switch (waves_per_wg) {
   case 4: return all_lds ? launch_pooled_t<256, true, false>(p, grid, stream) : launch_pooled_t<256, false, false>(p, grid, stream);
   case 8: return all_lds ? launch_pooled_t<512, true, false>(p, grid, stream) : launch_pooled_t<512, false, false>(p, grid, stream);
+  case 12: return all_lds ? launch_pooled_t<768, true, false>(p, grid, stream) : launch_pooled_t<768, false, false>(p, grid, stream);
   case 16: return all_lds ? launch_pooled_t<1024, true, false>(p, grid, stream) : launch_pooled_t<1024, false, false>(p, grid, stream);
   default: return hipErrorInvalidValue;
   }
@@ -782,8 +813,8 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
 // the first launch: ~0.5 ms that would otherwise land in the first timed frame).
 void warm_render_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<512, true, false>);
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<512, false, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<768, true, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false>);
   (void)hipFuncGetAttributes(&a, (const void *)tile_order_kernel);
 }
 

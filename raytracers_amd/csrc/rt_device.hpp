@@ -8,6 +8,9 @@
 namespace rtk {
 
 constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>= any LBVH height)
+// pooled_kernel: fixed part of a wave's LDS region in dwords: ray table 3 x 64 float4, hit keys
+// 64 x u64, counters 64, dump 4 (then the box stack and the leaf list)
+constexpr int kPooledWaveFixedDw = 768 + 128 + 64 + 4;
 
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)

@@ -108,10 +108,11 @@ class ShardedStep:
                 self.recv_all = torch.empty((self.world, self.total), dtype=torch.int32, device=self.device)
                 self.recv = [self.recv_all[p] for p in range(self.world)]
 
-    def render(self, events=None):
+    def render(self, events=None, gather_events=None):
         """One step.  Returns the list of full image tensors on rank dst, None elsewhere.
         `events`: optional list (one per frame) of (start, end) torch.cuda.Event pairs recorded
-        around this rank's kernel of that frame."""
+        around this rank's kernel of that frame; `gather_events`: an optional (start, end) pair
+        recorded around the exchange (gather + assembly on rank dst)."""
         for i, (render_part, _, _) in enumerate(self.frames):
             if events is not None and events[i] is not None:
                 events[i][0].record()
@@ -120,6 +121,15 @@ class ShardedStep:
                 events[i][1].record()
         if self.direct:
             return self.images
+        if gather_events is not None:
+            gather_events[0].record()
+        try:
+            return self._exchange()
+        finally:
+            if gather_events is not None:
+                gather_events[1].record()
+
+    def _exchange(self):
         if self.host_staged:
             send_h = self.send.cpu()      # synchronises with the renders on the current stream
             recv_h = [torch.empty_like(send_h) for _ in range(self.world)] if self.rank == self.dst else None

@@ -604,7 +604,57 @@ def test_bench_line_contract(tmp_path, force_gather):
     assert d["value"] > 100 and "workload" in d["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
-    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert d["verified"] is True and d["verified_images"] >= 2 * 6 + 2   # every lane's two images + the serial lane's
+    assert d["serial_value"] > 100 and set(d["serial_ms_per_frame"]) == {"rgbbox_1000x1000", "irreg_1000x1000"}
+    rf = d["roofline"]
+    if rf.get("stale_pmc"):
+        # profiles/pmc.json was measured on other kernel sources: bench.py must refuse it, not quote it
+        assert rf["achieved"] is None and rf["frac"] is None
+    else:
+        assert rf["bound"] == "valu_issue" and 0.0 < rf["frac"] <= 1.0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+        assert 0.0 < rf["mix"]["valu_pipe_busy"] <= 1.05
+
+
+def test_bench_refuses_wrong_pixels(tmp_path):
+    """The verification of the timed launches must be able to fail: with a wrong expected checksum
+    bench.py exits non-zero and prints no JSON line."""
+    import sys
+    code = ("import sys, bench; bench.FRAME_CHECKSUM[('irreg', 1000, 1000)] ^= 1; "
+            "sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-serial-extra']; bench.main()")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert "VERIFICATION FAILED" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_configuration_is_bit_exact(R):
+    """The exact configuration bench.py times -- 1000x1000, grid_div=4, deep_class=0, many contexts on their own
+    streams with frames in flight -- against the oracle's checksums, every lane, every frame."""
+    import torch
+    import bench
+    n = 12
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    cks = bench.Checksummer(torch.device("cuda", 0))
+    lanes = []
+    for st in streams:
+        ctx = R.Context(0, st.cuda_stream)
+        ctx.set_option("grid_div", 4)
+        ctx.set_option("deep_class", 0)
+        ps = [(s, R.prepare_scene(1000, 1000, ctx.scene(s)), torch.full((1000, 1000), 0x5a5a5a5a, dtype=torch.int32, device="cuda"))
+              for s in ("rgbbox", "irreg")]
+        lanes.append((ctx, ps))
+    for rep in range(3):           # first frame records the tile order, later ones use it; all overlapped
+        for ctx, ps in lanes:
+            for s, p, img in ps:
+                R.render_into(img.data_ptr(), 1000, 1000, p)
+    torch.cuda.synchronize()
+    for ctx, ps in lanes:
+        for s, p, img in ps:
+            assert cks(img) == bench.FRAME_CHECKSUM[(s, 1000, 1000)], s
+    for ctx, ps in lanes:
+        for s, p, img in ps:
+            p.free()
+        ctx.close()
 
 
 # ---------------------------------------------------------------- multi-rank on one GPU ---

@@ -90,3 +90,22 @@ def test_rust_algorithm_port_is_a_plausible_renderer():
         ref, cnt = O.OracleScene(name).render(200, 200)
         assert (px == ref).mean() > 0.97
         assert abs(rays - cnt["rays"]) < 0.02 * cnt["rays"]
+
+
+@pytest.mark.parametrize("scene", ["rgbbox", "irreg"])
+def test_checksums_of_the_bench_frames(scene):
+    """bench.py verifies every timed launch against FRAME_CHECKSUM / FRAME_WORK: both tables must be
+    the oracle's own results for the 1000x1000 frames of the headline metric."""
+    import bench
+    px, cnt = O.OracleScene(scene).render(1000, 1000)
+    assert O.checksum(px) == bench.FRAME_CHECKSUM[(scene, 1000, 1000)]
+    assert (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"]) == bench.FRAME_WORK[(scene, 1000, 1000)]
+
+
+def test_device_checksum_formula_matches_the_sequential_one():
+    """bench.Checksummer evaluates c = c * 31 + pixel as a wrapping polynomial (torch, any device)."""
+    import torch
+    import bench
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 1 << 24, size=(37, 53), dtype=np.int32)
+    assert bench.Checksummer(torch.device("cpu"))(torch.from_numpy(img)) == O.checksum(img)
