@@ -20,7 +20,11 @@ $(OBJ)/bvh_build.o: $(CSRC)/bvh_build.hip $(CSRC)/rt_device.hpp $(CSRC)/lane_cor
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h
+$(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_internal.hpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/multi_gpu.o: $(CSRC)/multi_gpu.cpp $(CSRC)/rt_internal.hpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp include/rt_mi355x.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -28,8 +32,9 @@ $(OBJ)/host_build.o: $(CSRC)/host_build.cpp $(CSRC)/rt_host.hpp
 	@mkdir -p $(OBJ)
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
-$(LIB): $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o $(OBJ)/api.o $(OBJ)/host_build.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+# (librccl is NOT linked: multi_gpu.cpp loads it on demand, so a single-GPU host needs no RCCL)
+$(LIB): $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o $(OBJ)/api.o $(OBJ)/multi_gpu.o $(OBJ)/host_build.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 # native harness (our own bench front-end; the reference's futhark/main.c links the same way)
 build/rtbench: tools/rtbench.c include/ray.h include/rt_mi355x.h $(LIB)

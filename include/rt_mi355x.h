@@ -46,6 +46,17 @@ enum {
  * enqueued on the caller's hipStream_t `hip_stream` -- NULL then means the default stream
  * (which is what torch.cuda.current_stream().cuda_stream is unless the caller switched). */
 int rt_context_create(rt_context **out, int device, void *hip_stream, int use_caller_stream);
+int rt_device_count(void);   /* usable HIP devices (0: none -- there is no CPU path) */
+/* One process, several devices: `devices[0..ndev)` are HIP device ordinals.  The context
+ * behaves like a single-device one on devices[0] -- scenes, prepare_scene, render, sync, values -- but
+ * prepare_scene replicates the scene on every device and rt_render / rt_render_image cut the frame into
+ * cyclic tiles of 8 rows (part i of ndev on devices[i]) and gather the parts on devices[0]: RCCL
+ * point-to-point over xGMI (librccl is loaded on demand), or peer copies (option "gather": 0 auto, 1 peer
+ * copies, 2 RCCL).  A device may be listed more than once (peer copies only): that is how the fan-out is
+ * tested on a one-GPU box.  rt_render_part with nparts > 1 is refused on such a context. */
+int rt_context_create_multi(rt_context **out, const int *devices, int ndev);
+int rt_context_num_devices(const rt_context *ctx);          /* 1 for an ordinary context */
+const char *rt_context_gather_mode(rt_context *ctx);        /* "none", "rccl" or "peer-copy" (static strings) */
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
 int rt_context_sync(rt_context *ctx);
@@ -93,7 +104,8 @@ int rt_render_part(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
                    int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev);
 /* The language-level surface itself: render_image objs width height cam (ray.fut:166) with an
  * explicit camera (12 floats: origin, llc, horizontal, vertical; ray.fut:88-91) instead of the
- * one prepare_scene derived.  cam12 == NULL: the prepared camera (then h, w must match it). */
+ * one prepare_scene derived.  cam12 == NULL: the prepared camera, at any h x w -- as `render h w
+ * prepared` does in the reference (ray.fut:246): the aspect ratio stays the one prepare_scene was given. */
 int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int64_t height, const float cam12[12],
                     int32_t max_depth, int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev);
 int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);

@@ -30,9 +30,15 @@ class Context:
     torch.cuda.current_stream().cuda_stream (0 = the default stream), so that launches order
     with torch work and torch.cuda.Event timing sees them."""
 
-    def __init__(self, device=-1, stream=None):
+    def __init__(self, device=-1, stream=None, devices=None):
+        """devices: a list of HIP device ordinals -> ONE context over several GPUs (rt_context_create_multi):
+        whole frames are cut into cyclic row tiles over them and gathered on devices[0]."""
         h = C.c_void_p()
-        rc = lib.rt_context_create(C.byref(h), int(device), C.c_void_p(stream or 0), 0 if stream is None else 1)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = lib.rt_context_create_multi(C.byref(h), arr, len(devices))
+        else:
+            rc = lib.rt_context_create(C.byref(h), int(device), C.c_void_p(stream or 0), 0 if stream is None else 1)
         if rc != 0 or not h.value:
             raise RtError(f"rt_context_create failed (code {rc}): no usable HIP device; "
                           "raytracers_amd has no CPU fallback")
@@ -56,6 +62,14 @@ class Context:
 
     def sync(self):
         self._check(lib.rt_context_sync(self._h))
+
+    @property
+    def num_devices(self):
+        return int(lib.rt_context_num_devices(self._h))
+
+    @property
+    def gather_mode(self):
+        return lib.rt_context_gather_mode(self._h).decode()
 
     def set_variant(self, v):
         self._check(lib.rt_context_set_variant(self._h, int(v)))

@@ -19,95 +19,9 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_device.hpp"
 #include "rt_host.hpp"
+#include "rt_internal.hpp"
 
-// ------------------------------------------------------------------------------------
-struct rt_context {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  std::string err;
-  int num_cu = 0;
-  int lds_bytes = 0;
-  std::string name;
-  // configuration
-  int variant = RT_VARIANT_AUTO;
-  int waves_per_wg = 0;     // persistent families: waves per workgroup (4, 8, 12, 16); 0 = chosen per scene (make_plan)
-  int wgs_per_cu = 1;       // persistent workgroups per CU (used with a configured waves_per_wg)
-  int thr_shade = 40;       // lanes with a finished fold / a vacant slot that trigger the shade phase
-  int thr_leaf = 24;        // phase vote: lanes holding deferred leaves that trigger the sphere phase
-  int lmax = 8;             // deferred-leaf capacity per lane
-  int lds_scene_bytes = -1; // < 0: as much as fits
-  int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
-  int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
-  int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
-  int grid_div = 0;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups; 0 = by frame size
-  int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
-  int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
-  int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
-  // ticket counter of the persistent family: monotonic across launches, never reset.
-  // A launch with C chunks and W waves performs exactly C + W atomic increments (every
-  // wave stops at its first out-of-range ticket), so the next launch's base is known.
-  unsigned *queue_dev = nullptr;
-  unsigned queue_base = 0;
-  unsigned long long *stats_dev = nullptr;
-  // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
-  struct UvTable {
-    int64_t w, h;
-    float *u, *v;
-  };
-  std::vector<UvTable> uv;
-  // Freed device blocks kept for the next prepare_scene (the reference's harness prepares the same
-  // scene `runs` times: hipMalloc / hipFree of a few MB cost more than the build itself).
-  struct Block {
-    char *p;
-    size_t bytes;
-  };
-  std::vector<Block> pool;
-  // One arena allocated with the context serves the blocks of small scenes (64 KiB granules, first
-  // fit): the first prepare_scene then pays no hipMalloc either.
-  char *arena = nullptr;
-  std::vector<unsigned char> arena_used;   // one flag per granule
-  char *pinned = nullptr;  // host-pinned block the build kernels report through
-  char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
-};
-
-struct rt_scene {
-  rt::SceneDesc desc;
-  // Device copy of the spheres, made by the first prepare_scene on a device (the reference's scene
-  // is a device-resident value too: futhark_entry_rgbbox/irreg build it there).
-  mutable float *dev = nullptr;
-  mutable int dev_id = -1;
-};
-
-// Tile-order state of one (image size, partition, depth, camera) view of a prepared scene.
-struct TileOrder {
-  int64_t h, w;
-  int32_t rows_per_tile, part, nparts, max_depth;
-  float cam[12];
-  int ntiles = 0;
-  int *cost = nullptr;    // [ntiles] record written by the render kernel
-  int *order = nullptr;   // [ntiles] ticket -> tile table for the next frame
-  bool valid = false;     // order[] has been computed from a previous frame
-};
-
-struct rt_prepared {
-  mutable std::vector<TileOrder> orders;
-  int64_t n = 0;
-  int64_t h = 0, w = 0;
-  rt::Camera cam{};
-  int height = 0;   // tree height
-  // canonical {L, I} on the device (SoA, as bvh.fut:28 lays them out)
-  float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
-  int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
-  // traversal copy
-  float4 *nodes = nullptr, *nodes64 = nullptr, *sph = nullptr, *col = nullptr;
-  char *block = nullptr;   // one device allocation behind all of the arrays above
-  size_t block_bytes = 0;
-  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-};
-
-namespace {
-
+namespace rti {
 int fail(rt_context *ctx, const std::string &msg) {
   if (ctx) ctx->err = msg;
   return 1;
@@ -115,11 +29,11 @@ int fail(rt_context *ctx, const std::string &msg) {
 int hip_fail(rt_context *ctx, hipError_t e, const char *what) {
   return fail(ctx, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define RT_HIP(ctx, call)                                        \
-  do {                                                           \
-    hipError_t e_ = (call);                                      \
-    if (e_ != hipSuccess) return hip_fail((ctx), e_, #call);     \
-  } while (0)
+}  // namespace rti
+using rti::fail;
+using rti::hip_fail;
+
+namespace {
 
 // ---- device-block pool -------------------------------------------------------------------------
 constexpr size_t kPoolMaxBlocks = 8, kPoolMaxBlockBytes = size_t(256) << 20;
@@ -302,14 +216,16 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   return 0;
 }
 
-int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
-                   int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr) {
+}  // namespace
+
+int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                        int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12) {
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
   if (!out_dev) return fail(ctx, "null output pointer");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30))
     return fail(ctx, "image size out of range");
-  if (!cam12 && (h != ps->h || w != ps->w))
-    return fail(ctx, "render size differs from the size the scene was prepared for (the camera aspect is fixed by prepare_scene)");
+  // (h, w) need not be the size given to prepare_scene: like the reference's `render h w {objs, cam}`
+  // (ray.fut:246) the frame is then traced through the camera prepare_scene derived (its aspect ratio)
   if (rows_per_tile <= 0 || nparts <= 0 || part < 0 || part >= nparts) return fail(ctx, "bad row-tile partition");
   if (max_depth < 0) return fail(ctx, "negative max_depth");
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -395,8 +311,7 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
   ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
   return 0;
 }
-
-}  // namespace
+using rti::enqueue_render;
 
 // ------------------------------------------------------------------------------------ context
 extern "C" void rt_context_destroy(rt_context *ctx);
@@ -453,6 +368,7 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
 
 extern "C" void rt_context_destroy(rt_context *ctx) {
   if (!ctx) return;
+  if (ctx->group) rti::group_destroy(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &t : ctx->uv) {
@@ -469,10 +385,16 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   delete ctx;
 }
 
+extern "C" int rt_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 extern "C" int rt_context_sync(rt_context *ctx) {
   if (!ctx) return 1;
+  if (ctx->group) return rti::group_sync(ctx);   // every frame ends on the parent's stream, synchronised last
   // Frames take well under a millisecond: poll for a while before falling back to the blocking
   // wait (whose wake-up latency alone is a sizeable fraction of a frame).
   const auto t0 = std::chrono::steady_clock::now();
@@ -490,11 +412,16 @@ extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
   if (!ctx) return 1;
   if (variant < RT_VARIANT_AUTO || variant > RT_VARIANT_POOLED) return fail(ctx, "unknown variant");
   ctx->variant = variant;
+  if (ctx->group) return rti::group_set_variant(ctx, variant);
   return 0;
 }
 
 extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return 1;
+  if (ctx->group) {
+    const int grc = rti::group_set_option(ctx, name, value);
+    if (grc >= 0) return grc;   // a group-only option, or a child refused the value
+  }
   const std::string k(name);
   const int v = static_cast<int>(value);
   if (k == "waves_per_wg") {
@@ -552,7 +479,9 @@ extern "C" int rt_context_device_info(const rt_context *ctx, int *device, int *n
 // ------------------------------------------------------------------------------------ scenes
 static int new_scene(rt_context *ctx, rt_scene **out, rt::SceneDesc &&d) {
   if (!ctx || !out) return fail(ctx, "null argument");
-  *out = new rt_scene{std::move(d)};
+  auto *s = new rt_scene;
+  s->desc = std::move(d);
+  *out = s;
   return 0;
 }
 extern "C" int rt_scene_rgbbox(rt_context *ctx, rt_scene **out) { return new_scene(ctx, out, rt::make_rgbbox()); }
@@ -576,11 +505,13 @@ extern "C" int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const floa
 extern "C" int64_t rt_scene_num_spheres(const rt_scene *scene) {
   return scene ? static_cast<int64_t>(scene->desc.spheres.size()) : 0;
 }
-extern "C" int rt_scene_free(rt_context *, rt_scene *scene) {
-  if (scene && scene->dev) {
-    (void)hipSetDevice(scene->dev_id);
-    (void)hipFree(scene->dev);
-  }
+extern "C" int rt_scene_free(rt_context *ctx, rt_scene *scene) {
+  if (scene)
+    for (auto &c : scene->copies) {
+      (void)hipSetDevice(c.device);
+      (void)hipFree(c.p);
+    }
+  if (ctx) (void)hipSetDevice(ctx->device);
   delete scene;
   return 0;
 }
@@ -619,34 +550,35 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   };
   if (ctx->gpu_build) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
-    if (scene->dev == nullptr || scene->dev_id != ctx->device) {
-      if (scene->dev) {
-        (void)hipSetDevice(scene->dev_id);
-        (void)hipFree(scene->dev);
-        scene->dev = nullptr;
-        (void)hipSetDevice(ctx->device);
-      }
-      const size_t sbytes = n * sizeof(rt::Sphere);
-      e = hipMalloc(reinterpret_cast<void **>(&scene->dev), sbytes + 16);
-      if (e == hipSuccess) {
-        if (sbytes + 16 <= kStageBytes) {
-          // small scene: through the pinned staging block and a copy kernel (a pageable hipMemcpy of
-          // a few hundred KB costs milliseconds)
-          std::memcpy(ctx->stage, scene->desc.spheres.data(), sbytes);
-          e = rtk::gpu_copy_from_pinned(scene->dev, ctx->stage, sbytes, ctx->stream);
-          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        } else {
-          e = hipMemcpy(scene->dev, scene->desc.spheres.data(), sbytes, hipMemcpyHostToDevice);
+    float *scene_dev = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(scene->mu);
+      for (const auto &c : scene->copies)
+        if (c.device == ctx->device) scene_dev = c.p;
+      if (!scene_dev) {
+        const size_t sbytes = n * sizeof(rt::Sphere);
+        e = hipMalloc(reinterpret_cast<void **>(&scene_dev), sbytes + 16);
+        if (e == hipSuccess) {
+          if (sbytes + 16 <= kStageBytes) {
+            // small scene: through the pinned staging block and a copy kernel (a pageable hipMemcpy of
+            // a few hundred KB costs milliseconds)
+            std::memcpy(ctx->stage, scene->desc.spheres.data(), sbytes);
+            e = rtk::gpu_copy_from_pinned(scene_dev, ctx->stage, sbytes, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+          } else {
+            e = hipMemcpy(scene_dev, scene->desc.spheres.data(), sbytes, hipMemcpyHostToDevice);
+          }
         }
+        if (e == hipSuccess) scene->copies.push_back({ctx->device, scene_dev});
+        else if (scene_dev) { (void)hipFree(scene_dev); scene_dev = nullptr; }
       }
-      scene->dev_id = ctx->device;
     }
     size_t tmp_bytes = rtk::gpu_build_scratch_bytes(static_cast<int>(n));
     char *tmp = nullptr;
     if (e == hipSuccess) e = pool_alloc(ctx, &tmp, &tmp_bytes);
     if (e == hipSuccess) {
       rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
-      e = rtk::gpu_build_bvh(scene->dev, static_cast<int>(n), o, tmp, ctx->pinned, ctx->stream, &ps->height, ps->root_lo,
+      e = rtk::gpu_build_bvh(scene_dev, static_cast<int>(n), o, tmp, ctx->pinned, ctx->stream, &ps->height, ps->root_lo,
                              ps->root_hi);
     }
     if (tmp) {
@@ -676,12 +608,18 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     rt_prepared_free(ctx, ps.release());
     return rc ? rc : hip_fail(ctx, e, "rt_prepare_scene");
   }
+  if (ctx->group)
+    if (int grc = rti::group_prepare(ctx, ps.get(), h, w, scene)) {
+      rt_prepared_free(ctx, ps.release());
+      return grc;
+    }
   *out = ps.release();
   return 0;
 }
 
 extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   if (!ps) return 0;
+  if (!ps->replicas.empty()) rti::group_prepared_free(ctx, ps);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -720,18 +658,31 @@ extern "C" int rt_prepared_get_camera(rt_context *ctx, const rt_prepared *ps, fl
 }
 
 // ------------------------------------------------------------------------------------ render
+// One frame (or one part of it) on the context: a multi-device context fans a WHOLE frame out over its
+// devices (multi_gpu.cpp); it does not nest a caller's partition inside its own.
+static int render_entry(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                        int32_t part, int32_t nparts, int32_t *out_dev, const float *cam12) {
+  if (ctx && ctx->group) {
+    if (!ps) return fail(ctx, "null prepared scene");
+    if (part != 0 || nparts != 1) return fail(ctx, "a multi-device context renders whole frames: it partitions them itself");
+    if (max_depth < 0) return fail(ctx, "negative max_depth");
+    return rti::group_render(ctx, ps, h, w, max_depth, out_dev, cam12);
+  }
+  return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false, cam12);
+}
+
 extern "C" int rt_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t *out_dev) {
-  return enqueue_render(ctx, ps, h, w, 50, 8, 0, 1, out_dev, false);
+  return render_entry(ctx, ps, h, w, 50, 8, 0, 1, out_dev, nullptr);
 }
 
 extern "C" int rt_render_part(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                               int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev) {
-  return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false);
+  return render_entry(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, nullptr);
 }
 
 extern "C" int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int64_t height, const float cam12[12],
                                int32_t max_depth, int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev) {
-  return enqueue_render(ctx, objs, height, width, max_depth, rows_per_tile, part, nparts, out_dev, false, cam12);
+  return render_entry(ctx, objs, height, width, max_depth, rows_per_tile, part, nparts, out_dev, cam12);
 }
 
 extern "C" int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts) {
@@ -856,13 +807,13 @@ extern "C" int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h
   if (!ctx || !ms_out || iters <= 0 || warmup < 0) return fail(ctx, "bad argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < warmup; ++i)
-    if (int rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false)) return rc;
+    if (int rc = render_entry(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, nullptr)) return rc;
   std::vector<hipEvent_t> ev(static_cast<size_t>(iters) + 1);
   for (auto &e : ev) RT_HIP(ctx, hipEventCreate(&e));
   RT_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   int rc = 0;
   for (int i = 0; i < iters && !rc; ++i) {
-    rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false);
+    rc = render_entry(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, nullptr);
     if (!rc && hipEventRecord(ev[i + 1], ctx->stream) != hipSuccess) rc = fail(ctx, "hipEventRecord failed");
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -901,6 +852,7 @@ extern "C" int rt_copy_to_host(rt_context *ctx, void *dst_host, const void *src_
 // ====================================================================================
 struct futhark_context_config {
   int device = -1;
+  std::vector<int> devices;   // more than one entry: a multi-device context (set_device("0-7") / "0,2,4"; env RT_DEVICES)
   int debugging = 0, logging = 0, profiling = 0;
 };
 struct futhark_context {
@@ -935,10 +887,31 @@ extern "C" void futhark_context_config_free(struct futhark_context_config *cfg) 
 extern "C" void futhark_context_config_set_debugging(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->debugging = flag; }
 extern "C" void futhark_context_config_set_logging(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->logging = flag; }
 extern "C" void futhark_context_config_set_profiling(struct futhark_context_config *cfg, int flag) { if (cfg) cfg->profiling = flag; }
+// "k" / "#k": HIP device k (the Futhark convention); "a-b" or "a,b,c": several devices = one multi-device
+// context (the frame is partitioned over them, include/rt_mi355x.h: rt_context_create_multi)
+static std::vector<int> parse_device_list(const char *s) {
+  std::vector<int> out;
+  while (*s) {
+    while (*s == ' ' || *s == ',' || *s == '#') ++s;
+    if (!*s) break;
+    char *end = nullptr;
+    const long a = std::strtol(s, &end, 10);
+    if (end == s || a < 0) return {};
+    s = end;
+    long b = a;
+    if (*s == '-') {
+      b = std::strtol(s + 1, &end, 10);
+      if (end == s + 1 || b < a) return {};
+      s = end;
+    }
+    for (long d = a; d <= b && out.size() < 64; ++d) out.push_back(static_cast<int>(d));
+  }
+  return out;
+}
 extern "C" void futhark_context_config_set_device(struct futhark_context_config *cfg, const char *s) {
   if (!cfg || !s) return;
-  if (*s == '#') ++s;
-  cfg->device = std::atoi(s);
+  cfg->devices = parse_device_list(s);
+  cfg->device = cfg->devices.empty() ? std::atoi(*s == '#' ? s + 1 : s) : cfg->devices[0];
 }
 
 extern "C" void futhark_context_config_set_num_threads(struct futhark_context_config *, int) {}
@@ -947,7 +920,11 @@ extern "C" void futhark_context_config_set_cache_file(struct futhark_context_con
 extern "C" struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) {
   auto ctx = std::make_unique<futhark_context>();
   ctx->logging = cfg ? (cfg->logging | cfg->debugging) : 0;
-  const int rc = rt_context_create(&ctx->rt, cfg ? cfg->device : -1, nullptr, 0);
+  // RT_DEVICES lets a harness that never calls set_device (futhark/main.c does not) use several GPUs
+  std::vector<int> devs = cfg ? cfg->devices : std::vector<int>();
+  if (const char *env = std::getenv("RT_DEVICES")) devs = parse_device_list(env);
+  const int rc = devs.size() > 1 ? rt_context_create_multi(&ctx->rt, devs.data(), static_cast<int>(devs.size()))
+                                 : rt_context_create(&ctx->rt, !devs.empty() ? devs[0] : (cfg ? cfg->device : -1), nullptr, 0);
   if (rc) {
     // Futhark returns a context whose error is set; main.c asserts it is NULL.
     ctx->pending = "libray_mi355x: cannot create a HIP context (code " + std::to_string(rc) + "); no CPU path exists";
@@ -976,8 +953,9 @@ extern "C" char *futhark_context_report(struct futhark_context *ctx) {
   int dev = -1, cus = 0, lds = 0;
   char name[64] = "";
   if (ctx && ctx->rt) rt_context_device_info(ctx->rt, &dev, &cus, &lds, name, sizeof name);
-  std::snprintf(buf, sizeof buf, "libray_mi355x: device %d (%s), %d CUs, %d B LDS/CU; %llu prepare_scene, %llu render calls\n",
-                dev, name, cus, lds, ctx ? (unsigned long long)ctx->prepares : 0ull,
+  std::snprintf(buf, sizeof buf, "libray_mi355x: device %d (%s), %d CUs, %d B LDS/CU; %d device(s), framebuffer gather: %s; %llu prepare_scene, %llu render calls\n",
+                dev, name, cus, lds, ctx && ctx->rt ? rt_context_num_devices(ctx->rt) : 0,
+                ctx && ctx->rt ? rt_context_gather_mode(ctx->rt) : "none", ctx ? (unsigned long long)ctx->prepares : 0ull,
                 ctx ? (unsigned long long)ctx->renders : 0ull);
   char *s = static_cast<char *>(std::malloc(std::strlen(buf) + 1));
   if (s) std::strcpy(s, buf);

@@ -1,0 +1,131 @@
+// rt_internal.hpp -- the library's internal data model, shared by api.cpp (single-device surface) and
+// multi_gpu.cpp (one process, several devices).  Not installed; the public surfaces are include/*.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_device.hpp"
+#include "rt_host.hpp"
+
+struct rt_group;   // multi_gpu.cpp: the devices behind a multi-device context
+
+// ------------------------------------------------------------------------------------
+struct rt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int num_cu = 0;
+  int lds_bytes = 0;
+  std::string name;
+  // configuration
+  int variant = RT_VARIANT_AUTO;
+  int waves_per_wg = 0;     // persistent families: waves per workgroup (4, 8, 12, 16); 0 = chosen per scene (make_plan)
+  int wgs_per_cu = 1;       // persistent workgroups per CU (used with a configured waves_per_wg)
+  int thr_shade = 40;       // lanes with a finished fold / a vacant slot that trigger the shade phase
+  int thr_leaf = 24;        // phase vote: lanes holding deferred leaves that trigger the sphere phase
+  int lmax = 8;             // deferred-leaf capacity per lane
+  int lds_scene_bytes = -1; // < 0: as much as fits
+  int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
+  int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
+  int grid_div = 0;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups; 0 = by frame size
+  int low_box = 0, thr_shade_low = 16, low_leaf = 64;   // pooled family: policy while the box stack is short
+  int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
+  int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
+  // ticket counter of the persistent family: monotonic across launches, never reset.
+  // A launch with C chunks and W waves performs exactly C + W atomic increments (every
+  // wave stops at its first out-of-range ticket), so the next launch's base is known.
+  unsigned *queue_dev = nullptr;
+  unsigned queue_base = 0;
+  unsigned long long *stats_dev = nullptr;
+  // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
+  struct UvTable {
+    int64_t w, h;
+    float *u, *v;
+  };
+  std::vector<UvTable> uv;
+  // Freed device blocks kept for the next prepare_scene (the reference's harness prepares the same
+  // scene `runs` times: hipMalloc / hipFree of a few MB cost more than the build itself).
+  struct Block {
+    char *p;
+    size_t bytes;
+  };
+  std::vector<Block> pool;
+  // One arena allocated with the context serves the blocks of small scenes (64 KiB granules, first
+  // fit): the first prepare_scene then pays no hipMalloc either.
+  char *arena = nullptr;
+  std::vector<unsigned char> arena_used;   // one flag per granule
+  rt_group *group = nullptr;   // multi-device context: the devices behind it (multi_gpu.cpp); this context is the first device's
+  char *pinned = nullptr;  // host-pinned block the build kernels report through
+  char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
+};
+
+struct rt_scene {
+  rt::SceneDesc desc;
+  // Device copies of the spheres, one per device, made by the first prepare_scene on that device (the
+  // reference's scene is a device-resident value too: futhark_entry_rgbbox/irreg build it there).
+  struct DevCopy {
+    int device;
+    float *p;
+  };
+  mutable std::mutex mu;                 // a multi-device prepare_scene uploads from several host threads
+  mutable std::vector<DevCopy> copies;
+};
+
+// Tile-order state of one (image size, partition, depth, camera) view of a prepared scene.
+struct TileOrder {
+  int64_t h, w;
+  int32_t rows_per_tile, part, nparts, max_depth;
+  float cam[12];
+  int ntiles = 0;
+  int *cost = nullptr;    // [ntiles] record written by the render kernel
+  int *order = nullptr;   // [ntiles] ticket -> tile table for the next frame
+  bool valid = false;     // order[] has been computed from a previous frame
+};
+
+struct rt_prepared {
+  mutable std::vector<TileOrder> orders;
+  int64_t n = 0;
+  int64_t h = 0, w = 0;
+  rt::Camera cam{};
+  int height = 0;   // tree height
+  // canonical {L, I} on the device (SoA, as bvh.fut:28 lays them out)
+  float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
+  int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
+  // traversal copy
+  float4 *nodes = nullptr, *nodes64 = nullptr, *sph = nullptr, *col = nullptr;
+  char *block = nullptr;   // one device allocation behind all of the arrays above
+  size_t block_bytes = 0;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
+};
+
+
+namespace rti {
+int fail(rt_context *ctx, const std::string &msg);
+int hip_fail(rt_context *ctx, hipError_t e, const char *what);
+// Enqueue one part of a frame on ctx's stream (single device).  cam12 == nullptr: the prepared camera.
+int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                   int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr);
+// multi_gpu.cpp
+int group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,
+                 const float *cam12);
+int group_prepare(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene);
+void group_prepared_free(rt_context *ctx, rt_prepared *ps);
+int group_sync(rt_context *ctx);
+int group_set_variant(rt_context *ctx, int variant);
+int group_set_option(rt_context *ctx, const char *name, int64_t value);
+void group_destroy(rt_context *ctx);
+}  // namespace rti
+
+#define RT_HIP(ctx, call)                                             \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) return rti::hip_fail((ctx), e_, #call);     \
+  } while (0)

@@ -536,6 +536,96 @@ def test_native_bench_runs(tmp_path):
     assert int((_read_ppm(ppm) != want).sum()) == 0
 
 
+def test_render_at_another_size_uses_the_prepared_camera(R, ctx):
+    """`render h w prepared` (ray.fut:246) accepts any size: the camera -- and so the aspect ratio -- is the
+    one prepare_scene derived.  Same pixels as render_image with that camera passed explicitly."""
+    ps = R.prepare_scene(120, 160, ctx.rgbbox())
+    a = R.render(90, 200, ps)
+    b = R.render_image(ps, 200, 90, ps.camera())
+    assert a.shape == (90, 200) and int((a != b).sum()) == 0
+    want, _ = _oracle("rgbbox").render(120, 160)
+    assert int((R.render(120, 160, ps) != want).sum()) == 0
+
+
+# ---------------------------------------------------------------- one process, several devices ---
+@pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 1000, 1000)])
+def test_multi_device_context_on_one_gpu(R, scene, h, w):
+    """rt_context_create_multi with the device listed three times: the whole fan-out (replicated prepare_scene,
+    cyclic row tiles on three streams, peer-copy gather, assembly) through the single-device entry points."""
+    import bench
+    mc = R.Context(devices=[0, 0, 0])
+    assert mc.num_devices == 3 and mc.gather_mode == "peer-copy"
+    ps = R.prepare_scene(h, w, mc.scene(scene))
+    want, _ = _oracle(scene).render(h, w)
+    for rep in range(3):                       # frames chase each other through the shared gather buffers
+        assert int((R.render(h, w, ps) != want).sum()) == 0, rep
+    if (scene, h, w) in bench.FRAME_CHECKSUM:
+        assert O.checksum(want) == bench.FRAME_CHECKSUM[(scene, h, w)]
+    # a smaller and then a larger frame: the gather buffers shrink-fit / regrow
+    for hh, ww in ((64, 80), (h + 16, w)):
+        ps2 = R.prepare_scene(hh, ww, mc.scene(scene))
+        w2, _ = _oracle(scene).render(hh, ww)
+        assert int((R.render(hh, ww, ps2) != w2).sum()) == 0
+        ps2.free()
+    # a caller's own partition is refused, knobs reach every device, BVH getters serve the first device
+    import torch
+    out = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    with pytest.raises(R.RtError, match="whole frames"):
+        R.render_into(out.data_ptr(), h, w, ps, part=0, nparts=2)
+    mc.set_option("thr_shade", 16)
+    mc.set_variant(R.VARIANT_PERSISTENT)
+    assert int((R.render(h, w, ps) != want).sum()) == 0
+    assert ps.bvh_arrays()["L"].shape == (ps.num_spheres, 7)
+    ps.free()
+    mc.close()
+
+
+def test_multi_device_rccl_gather_on_one_gpu(R):
+    """gather=2 forces the RCCL path even for a single device: librccl is loaded on demand, one communicator,
+    the part travels by grouped ncclSend / ncclRecv (to self) into the stacked buffer and is assembled from there."""
+    mc = R.Context(devices=[0])
+    mc.set_option("gather", 2)
+    ps = R.prepare_scene(200, 200, mc.irreg())
+    want, _ = _oracle("irreg").render(200, 200)
+    for rep in range(3):
+        assert int((R.render(200, 200, ps) != want).sum()) == 0
+    assert mc.gather_mode == "rccl"
+    ps.free()
+    mc.close()
+
+
+def test_multi_device_real_devices(R):
+    """With two or more GPUs present: the same through RCCL over xGMI (skipped on a one-GPU box)."""
+    from raytracers_amd._lib import lib
+    n = int(lib.rt_device_count())
+    if n < 2:
+        pytest.skip("one GPU")
+    mc = R.Context(devices=list(range(n)))
+    assert mc.gather_mode == "rccl"
+    for scene, h, w in (("irreg", 4000, 4000), ("rgbbox", 1000, 1000)):
+        ps = R.prepare_scene(h, w, mc.scene(scene))
+        img = R.render(h, w, ps)
+        import bench
+        assert O.checksum(img) == bench.FRAME_CHECKSUM[(scene, h, w)]
+        ps.free()
+    mc.close()
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0-0"])
+def test_reference_harness_unmodified_multi_device(devices, tmp_path):
+    """The reference's own main.c binary, untouched, on a multi-device context: RT_DEVICES picks the devices
+    (main.c never calls futhark_context_config_set_device)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "futhark_main")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/futhark_main was not prebuilt (needs /root/reference)")
+    ppm = str(tmp_path / "out.ppm")
+    out = subprocess.run([exe, "-s", "irreg", "-n", "300", "-m", "400", "-r", "3", "-f", ppm], capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ, RT_DEVICES=devices))
+    assert out.returncode == 0, out.stdout + out.stderr
+    want, _ = _oracle("irreg").render(300, 400)
+    assert int((_read_ppm(ppm) != want).sum()) == 0
+
+
 # ---------------------------------------------------------------- error behaviour ---------
 def test_errors_are_codes_with_messages(R, ctx):
     """Every entry returns non-zero on failure and leaves a message (the reference's harness
@@ -543,8 +633,6 @@ def test_errors_are_codes_with_messages(R, ctx):
     import torch
     ps = R.prepare_scene(32, 48, ctx.rgbbox())
     out = torch.full((32, 48), 123, dtype=torch.int32, device="cuda")
-    with pytest.raises(R.RtError, match="prepared for"):       # the camera aspect is fixed by prepare_scene
-        R.render_into(out.data_ptr(), 48, 32, ps)
     with pytest.raises(R.RtError, match="partition"):
         R.render_into(out.data_ptr(), 32, 48, ps, part=3, nparts=3)
     with pytest.raises(R.RtError, match="null"):

@@ -10,7 +10,9 @@
  *   rtbench -s rgbbox|irreg|big|floor:N:K -n H -m W -r RUNS -d MAX_DEPTH -v VARIANT
  *           -o name=value (repeatable) -f out.ppm -g PARTS -L LANES
  *
- * -L LANES > 1 adds a throughput figure: LANES contexts (own stream, own prepared scene, own
+ * -g N: ONE multi-device context over devices 0..N-1 (rt_context_create_multi: cyclic row tiles, RCCL /
+ * peer-copy gather on device 0); with fewer than N devices present the N parts all run on device 0
+ * (test mode).  -L LANES > 1 adds a throughput figure: LANES contexts (own stream, own prepared scene, own
  * framebuffer each) keep one frame in flight each, all enqueued before any is awaited.
  */
 #include <getopt.h>
@@ -68,7 +70,15 @@ int main(int argc, char **argv) {
     }
   }
   rt_context *ctx = NULL;
-  if (rt_context_create(&ctx, -1, NULL, 0) != 0) { fprintf(stderr, "no HIP device\n"); return 1; }
+  if (parts > 1) {
+    int devs[64];
+    const int have = rt_device_count();
+    if (parts > 64) parts = 64;
+    for (int i = 0; i < parts; i++) devs[i] = have >= parts ? i : 0;
+    if (rt_context_create_multi(&ctx, devs, parts) != 0) { fprintf(stderr, "cannot create the multi-device context\n"); return 1; }
+    printf("Multi-device context: %d parts on %s; framebuffer gather: %s\n", parts,
+           have >= parts ? "devices 0..N-1" : "device 0 only (fewer devices present: test mode)", rt_context_gather_mode(ctx));
+  } else if (rt_context_create(&ctx, -1, NULL, 0) != 0) { fprintf(stderr, "no HIP device\n"); return 1; }
   CHECK(ctx, rt_context_set_variant(ctx, variant));
   for (int i = 0; i < nopts; i++) {
     char key[64];
@@ -110,16 +120,7 @@ int main(int argc, char **argv) {
   CHECK(ctx, rt_context_sync(ctx));
   t0 = now_s();
   for (int i = 0; i < runs; i++) {
-    if (parts == 1) {
-      CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, 0, 1, img));
-    } else {
-      /* all parts back to back on this one device: exercises the row-tile partition */
-      int64_t off = 0;
-      for (int p = 0; p < parts; p++) {
-        CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, p, parts, img + off));
-        off += rt_part_rows(h, 8, p, parts) * w;
-      }
-    }
+    CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, 0, 1, img));   /* a multi-device context fans the frame out itself */
     CHECK(ctx, rt_context_sync(ctx));
   }
   double t_render = (now_s() - t0) / runs;
@@ -187,21 +188,8 @@ int main(int argc, char **argv) {
 
   if (ppm) {
     int32_t *host = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
-    if (parts == 1) {
-      CHECK(ctx, rt_copy_to_host(ctx, host, img, (int64_t)sizeof(int32_t) * h * w));
-    } else {
-      int32_t *full = NULL;
-      CHECK(ctx, rt_device_alloc(ctx, (void **)&full, (int64_t)sizeof(int32_t) * h * w));
-      int64_t off = 0;
-      for (int p = 0; p < parts; p++) {
-        /* img was reused by the timed full-frame launches above: render the parts again */
-        CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, p, parts, img + off));
-        CHECK(ctx, rt_place_part(ctx, h, w, 8, p, parts, img + off, full));
-        off += rt_part_rows(h, 8, p, parts) * w;
-      }
-      CHECK(ctx, rt_copy_to_host(ctx, host, full, (int64_t)sizeof(int32_t) * h * w));
-      rt_device_free(ctx, full);
-    }
+    CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, 0, 1, img));
+    CHECK(ctx, rt_copy_to_host(ctx, host, img, (int64_t)sizeof(int32_t) * h * w));
     printf("Writing image to %s.\n", ppm);
     write_ppm(ppm, host, h, w);
     free(host);
