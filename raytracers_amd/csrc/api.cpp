@@ -395,17 +395,26 @@ extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->
 extern "C" int rt_context_sync(rt_context *ctx) {
   if (!ctx) return 1;
   if (ctx->group) return rti::group_sync(ctx);   // every frame ends on the parent's stream, synchronised last
-  // Frames take well under a millisecond: poll for a while before falling back to the blocking
-  // wait (whose wake-up latency alone is a sizeable fraction of a frame).
+  // Frames take well under a millisecond: poll briefly (a frame's worth) before falling back to the
+  // blocking wait, whose wake-up latency alone is a sizeable fraction of a frame.  The poll is short on
+  // purpose: a process with many contexts must not burn a host core per context.
   const auto t0 = std::chrono::steady_clock::now();
+  hipError_t q;
   for (;;) {
-    const hipError_t q = hipStreamQuery(ctx->stream);
-    if (q == hipSuccess) return 0;
-    if (q != hipErrorNotReady) return hip_fail(ctx, q, "hipStreamQuery");
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+    q = hipStreamQuery(ctx->stream);
+    if (q != hipErrorNotReady) break;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(800)) {
+      q = hipStreamSynchronize(ctx->stream);
+      break;
+    }
   }
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  if (q == hipSuccess) return 0;
+  // A launch that died leaves the device-side ticket counter out of step with queue_base (the host
+  // assumes every launch performs nchunks + waves increments): every later frame would draw
+  // out-of-range tickets and silently render nothing.  Re-zero both.
+  (void)hipGetLastError();
+  if (hipMemset(ctx->queue_dev, 0, 256) == hipSuccess) ctx->queue_base = 0;
+  return hip_fail(ctx, q, "stream synchronisation (the ticket counter was reset)");
 }
 
 extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
@@ -722,12 +731,13 @@ extern "C" int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t row
 extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                                uint64_t stats3[3]) {
   if (!ctx || !ps || !stats3) return fail(ctx, "null argument");
+  if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30)) return fail(ctx, "image size out of range");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   int32_t *tmp = nullptr;
   RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(int32_t) * static_cast<size_t>(h) * w));
-  RT_HIP(ctx, hipMemsetAsync(ctx->stats_dev, 0, 3 * sizeof(unsigned long long), ctx->stream));
-  int rc = enqueue_render(ctx, ps, h, w, max_depth, 8, 0, 1, tmp, true);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipMemsetAsync(ctx->stats_dev, 0, 3 * sizeof(unsigned long long), ctx->stream);
+  int rc = e == hipSuccess ? enqueue_render(ctx, ps, h, w, max_depth, 8, 0, 1, tmp, true) : 0;
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   unsigned long long host[3] = {0, 0, 0};
   if (!rc && e == hipSuccess) e = hipMemcpy(host, ctx->stats_dev, sizeof host, hipMemcpyDeviceToHost);
   (void)hipFree(tmp);
@@ -752,11 +762,19 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   if (rc) return rc;
   const int nw = pl.grid * pl.waves;
   if (nw > max_waves) return fail(ctx, "trace buffer too small");
+  if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30)) return fail(ctx, "image size out of range");
   int32_t *tmp = nullptr;
   unsigned long long *trace = nullptr;
   RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(int32_t) * static_cast<size_t>(h) * w));
-  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * 8 * static_cast<size_t>(nw)));
-  RT_HIP(ctx, hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), ctx->stream));
+  if (hipError_t em = hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * 8 * static_cast<size_t>(nw)); em != hipSuccess) {
+    (void)hipFree(tmp);
+    return hip_fail(ctx, em, "hipMalloc(trace)");
+  }
+  if (hipError_t em = hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), ctx->stream); em != hipSuccess) {
+    (void)hipFree(tmp);
+    (void)hipFree(trace);
+    return hip_fail(ctx, em, "hipMemsetAsync(trace)");
+  }
   rtk::KParams p{};
   p.nodes = ps->nodes; p.nodes64 = ps->nodes64; p.sph = ps->sph; p.col = ps->col;
   std::copy(ps->root_lo, ps->root_lo + 3, p.root_lo);

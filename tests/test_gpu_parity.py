@@ -135,6 +135,28 @@ def test_big_scene_million_spheres(R, ctx):
         assert int((R.render(512, 512, ps) != ref).sum()) == 0, v
 
 
+def test_big_2000_at_size(R, ctx):
+    """BASELINE configs[4] AT ITS STATED SIZE: 10^6 spheres, 2000x2000 (only the top of the 64 MB node array is LDS
+    resident), every pixel against the oracle, checksum 3a198726 and the work counters of SURVEY.md 8d; also through
+    a three-part multi-device context (configs[4] names 8 GPUs; one is present here)."""
+    import bench
+    ctx.set_variant(0)
+    ps = R.prepare_scene(2000, 2000, ctx.scene("big"))
+    px = R.render(2000, 2000, ps)
+    ref, cnt = _oracle("big").render(2000, 2000)
+    assert int((px != ref).sum()) == 0
+    assert O.checksum(px) == bench.FRAME_CHECKSUM[("big", 2000, 2000)] == 0x3A198726
+    st = ps.stats()
+    assert (st["rays"], st["box_tests"], st["leaf_tests"]) == bench.FRAME_WORK[("big", 2000, 2000)] == \
+        (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"])
+    ps.free()
+    mc = R.Context(devices=[0, 0, 0])
+    ps = R.prepare_scene(2000, 2000, mc.scene("big"))
+    assert O.checksum(R.render(2000, 2000, ps)) == 0x3A198726
+    ps.free()
+    mc.close()
+
+
 @pytest.mark.parametrize("variant", [1, 3])
 def test_host_built_scene_renders_identically(R, variant):
     """The two builders number the traversal copy differently (breadth-first vs by depth); pixels
@@ -702,6 +724,26 @@ def test_bench_line_contract(tmp_path, force_gather):
         assert rf["bound"] == "valu_issue" and 0.0 < rf["frac"] <= 1.0
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
         assert 0.0 < rf["mix"]["valu_pipe_busy"] <= 1.05
+
+
+def test_bench_line_two_ranks_sharing_the_gpu():
+    """The driver's N > 1 command line (torch.distributed.run, one rank per GPU) with both ranks on cuda:0
+    (RT_SHARE_GPU=1: gloo, host-staged gather): the sharded steps are verified against the oracle's checksums and the
+    line carries the irreg 4000x4000 sub-record north_star states its scaling target on."""
+    import json
+    import sys
+    env = dict(os.environ, RT_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "strong"
+    r = d["irreg_4000"]
+    assert r["verified"] is True and r["ms_per_frame"] > 0 and r["Mray_s"] > 0
+    assert r["render_us_per_rank"]["slowest"] >= r["render_us_per_rank"]["fastest"] > 0 and r["gather_and_assemble_us_rank0"] > 0
 
 
 def test_bench_refuses_wrong_pixels(tmp_path):

@@ -92,14 +92,16 @@ def test_rust_algorithm_port_is_a_plausible_renderer():
         assert abs(rays - cnt["rays"]) < 0.02 * cnt["rays"]
 
 
-@pytest.mark.parametrize("scene", ["rgbbox", "irreg"])
-def test_checksums_of_the_bench_frames(scene):
-    """bench.py verifies every timed launch against FRAME_CHECKSUM / FRAME_WORK: both tables must be
-    the oracle's own results for the 1000x1000 frames of the headline metric."""
+@pytest.mark.parametrize("scene,h,w", [("rgbbox", 1000, 1000), ("irreg", 1000, 1000), ("irreg", 4000, 4000), ("big", 2000, 2000)])
+def test_checksums_of_the_bench_frames(scene, h, w):
+    """bench.py (and the GPU tests at BASELINE.json's full sizes) verify launches against FRAME_CHECKSUM /
+    FRAME_WORK: both tables must be the oracle's own results -- the 1000x1000 frames of the headline metric,
+    configs[3] (irreg 4000x4000) and configs[4] (10^6 spheres = the irreg generator with n = 1000, k = 6000, at 2000x2000)."""
     import bench
-    px, cnt = O.OracleScene(scene).render(1000, 1000)
-    assert O.checksum(px) == bench.FRAME_CHECKSUM[(scene, 1000, 1000)]
-    assert (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"]) == bench.FRAME_WORK[(scene, 1000, 1000)]
+    sc = O.OracleScene("floor", n=1000, k=6000.0) if scene == "big" else O.OracleScene(scene)
+    px, cnt = sc.render(h, w)
+    assert O.checksum(px) == bench.FRAME_CHECKSUM[(scene, h, w)]
+    assert (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"]) == bench.FRAME_WORK[(scene, h, w)]
 
 
 def test_device_checksum_formula_matches_the_sequential_one():
