@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
-    ap.add_argument("--frames-in-flight", type=int, default=24, help="independent steps enqueued concurrently (streams); capped by --steps")
+    ap.add_argument("--frames-in-flight", type=int, default=10, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
     ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
@@ -285,7 +285,10 @@ def main():
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
-    # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).
+    # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).  Ten lanes at
+    # a quarter-size launch each were the best of {6, 10, 20} x grid_div {2, 4, 8} at the driver's K = 20
+    # (gpurun_out sweep): a workgroup fills a CU's LDS, so only 4 quarter-size launches are resident at a
+    # time and more lanes only lengthen the queue -- and the drain at the end of the bracket.
     S = max(1, min(args.frames_in_flight, args.steps))
     # With many frames in flight a launch need not fill the machine by itself: a quarter of the
     # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is

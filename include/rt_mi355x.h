@@ -128,9 +128,10 @@ int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_p
 int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                     uint64_t stats3[3]);
 
-/* Diagnostic: one instrumented launch of the pooled kernel; per wave 8 x u64 = {clock at start,
- * at queue exhaustion, at exit, #BOX ops, #LEAF ops, #SHADE ops, (box items << 32 | leaf items),
- * deepest bounce chain finished}. */
+/* Diagnostic: one instrumented launch of the pooled kernel; per wave 8 x u64 = {wall clock (100 MHz ticks,
+ * chip-wide) at start, at queue exhaustion, at exit; #BOX | #LEAF << 21 | #SHADE << 42 operations; shader
+ * cycles lived; 0; (box items << 32 | leaf items); deepest bounce chain finished | max box stack << 16 |
+ * max leaf list << 32}. */
 int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                     uint64_t *records, int32_t max_waves, int32_t *num_waves);
 

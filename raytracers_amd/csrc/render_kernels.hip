@@ -374,9 +374,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // busy with 63 other rays' work.
   bool hold = false;
   // instrumented build only: per-wave timeline (rt_render_trace)
-  unsigned long long tr_t0 = 0, tr_exh = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
+  unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   int tr_maxdepth = 0, tr_maxbox = 0, tr_maxleaf = 0;
-  if (STATS) tr_t0 = clock64();
+  if (STATS) {
+    tr_t0 = wall_clock64();   // 100 MHz, one counter for the whole chip (clock64 is per XCD)
+    tr_c0 = clock64();
+  }
 
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -388,20 +391,24 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       tr_maxleaf = nleaf > tr_maxleaf ? nleaf : tr_maxleaf;
     }
     bool drain = false;    // the leaf list must be emptied before folds can be finished
+    // a short box stack means idle lanes in the coming BOX operations: be more eager to start
+    // new folds then (thr_shade_low applies while nbox < low_box)
+    const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
     if (nbox < 64 && nleaf < 64) {
-      // not a full wave of work in either list: look at completed folds / vacant slots.  With
-      // leaf items pending `done` over-estimates (the counter covers inner-node items only): it
+     // Not a full wave of work in either list: look at completed folds / vacant slots -- unless even
+     // ALL live slots being finished could not reach the threshold (a wave nursing a few deep bounce
+     // chains: the look costs an LDS round trip per operation on the frame's critical path).
+     const unsigned long long m_live = bal(pix >= 0);
+     if (hold && m_live == 0ull) {   // the deep tile is finished: back to normal service
+       hold = false;
+       __builtin_amdgcn_s_setprio(0);
+     }
+     const bool vacant = (pix < 0) & !exhausted & !hold;
+     if (nbox == 0 || (int)__popcll(m_live | bal(vacant)) >= thr) {
+      // With leaf items pending `done` over-estimates (the counter covers inner-node items only): it
       // then only decides whether to drain the leaf list now.
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
-      if (hold && bal(pix >= 0) == 0ull) {   // the deep tile is finished: back to normal service
-        hold = false;
-        __builtin_amdgcn_s_setprio(0);
-      }
-      const bool vacant = (pix < 0) & !exhausted & !hold;
       const int ns = __popcll(bal(done | vacant));
-      // a short box stack means idle lanes in the coming BOX operations: be more eager to start
-      // new folds then (thr_shade_low applies while nbox < low_box)
-      const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
       if (ns >= thr || nbox == 0) {
         if (nleaf > 0) {
           drain = true;
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               t = __builtin_amdgcn_readfirstlane(t);
               if (t >= (unsigned)p.nchunks) {
                 exhausted = true;
-                if (STATS) tr_exh = clock64();
+                if (STATS) tr_exh = wall_clock64();
                 break;
               }
               q_next = t * 64u;
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           continue;
         }
       }
+     }
     }
     if (drain || nleaf >= 64 || nbox == 0 || (nbox < p.low_box && nleaf >= p.low_leaf)) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
@@ -612,13 +620,15 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     atomicAdd(&p.stats[1], n_box);
     atomicAdd(&p.stats[2], n_sph);
     if (p.trace != nullptr) {
-      const unsigned long long t_end = clock64();
+      const unsigned long long t_end = wall_clock64(), c_end = clock64();
       int md = tr_maxdepth;
       for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(md, o); md = other > md ? other : md; }
       if (lane == 0) {
         unsigned long long *rec = p.trace + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
         rec[0] = tr_t0; rec[1] = tr_exh; rec[2] = t_end;
-        rec[3] = tr_ops[0]; rec[4] = tr_ops[1]; rec[5] = tr_ops[2];
+        rec[3] = tr_ops[0] | (tr_ops[1] << 21) | (tr_ops[2] << 42);
+        rec[4] = c_end - tr_c0;   // shader cycles of this wave's life
+        rec[5] = 0;
         rec[6] = (tr_items[0] << 32) | tr_items[1];
         rec[7] = (unsigned long long)md | ((unsigned long long)tr_maxbox << 16) | ((unsigned long long)tr_maxleaf << 32);
       }

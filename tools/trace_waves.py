@@ -24,26 +24,25 @@ n = C.c_int32()
 ctx._check(lib.rt_render_trace(ctx._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
 rec = rec[: n.value].astype(np.int64)
 t0 = rec[:, 0].min()
-start, exh, end = rec[:, 0] - t0, rec[:, 1] - t0, rec[:, 2] - t0
+TICK_US = 0.01   # wall clock: 100 MHz
+start, exh, end = (rec[:, 0] - t0) * TICK_US, (rec[:, 1] - t0) * TICK_US, (rec[:, 2] - t0) * TICK_US
 exh = np.where(rec[:, 1] > 0, exh, end)
-print(f"{scene} {w}x{h}: {n.value} waves; kernel span {end.max()} clk")
+print(f"{scene} {w}x{h}: {n.value} waves; first wave start -> last wave end {end.max():.1f} us")
 for name, v in (("start", start), ("queue exhausted", exh), ("end", end)):
-    print(f"  {name:16s} min {v.min():9d}  p50 {int(np.median(v)):9d}  p90 {int(np.percentile(v, 90)):9d}  max {v.max():9d}")
-life = end - start
-print(f"  mean wave lifetime {life.mean():.0f} clk = {life.mean() / end.max():.2f} of the span")
+    print(f"  {name:16s} min {v.min():8.1f}  p50 {np.median(v):8.1f}  p90 {np.percentile(v, 90):8.1f}  max {v.max():8.1f} us")
+life_us = end - start
+print(f"  mean wave lifetime {life_us.mean():.1f} us = {life_us.mean() / end.max():.2f} of the span; shader clock while alive {np.mean(rec[:, 4] / np.maximum(life_us, 0.01)):.0f} MHz")
 maxbox, maxleaf = (rec[:, 7] >> 16) & 0xFFFF, (rec[:, 7] >> 32) & 0xFFFF
 rec[:, 7] &= 0xFFFF
 print(f"  box stack high-water mark: max {maxbox.max()} p99 {int(np.percentile(maxbox, 99))} p50 {int(np.median(maxbox))} items"
       f" (capacity 64*(height+3)); leaf list: max {maxleaf.max()}")
-ops = rec[:, 3:6]
+ops = np.stack([rec[:, 3] & 0x1FFFFF, (rec[:, 3] >> 21) & 0x1FFFFF, (rec[:, 3] >> 42) & 0x1FFFFF], axis=1)
 items_box, items_leaf = rec[:, 6] >> 32, rec[:, 6] & 0xFFFFFFFF
 tot = ops.sum(axis=1)
 print(f"  ops/wave: mean {tot.mean():.0f} max {tot.max()}  (BOX {ops[:,0].sum()} LEAF {ops[:,1].sum()} SHADE {ops[:,2].sum()})")
 print(f"  lane efficiency: BOX {items_box.sum() / (64.0 * ops[:,0].sum()):.3f} LEAF {items_leaf.sum() / (64.0 * ops[:,1].sum()):.3f}")
-print(f"  clk per op (lifetime / ops): mean {(life / np.maximum(tot, 1)).mean():.0f}")
-late = np.argsort(end)[-8:]
+print(f"  shader cycles per op (cycles lived / ops): mean {(rec[:, 4] / np.maximum(tot, 1)).mean():.0f}")
+late = np.argsort(end)[-6:]
 for i in late[::-1]:
-    print(f"    wave {i:5d}: end {end[i]:9d} exhausted {exh[i]:9d} ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}"
-          f" drain clk/op {(end[i]-exh[i]) / max(1, 1):.0f}")
-# drain phase: ops after exhaustion are unknown per wave, but the time is:
-print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.0f} max {np.max(end - exh)} clk")
+    print(f"    wave {i:5d}: start {start[i]:7.1f} exhausted {exh[i]:7.1f} end {end[i]:7.1f} us; ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}")
+print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.1f} max {np.max(end - exh):.1f} us")
