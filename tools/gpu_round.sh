@@ -29,7 +29,7 @@ echo "== reference harness (futhark/main.c, unmodified) on our library"
 for s in rgbbox irreg; do timeout 120 ./oracle/_ref/futhark_main -s $s -n 1000 -m 1000 2>&1 | grep -E "construction|Rendering"; done
 } > $OUT/rtbench.log 2>&1
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/rocprof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-serial-extra > $OUT/rocprof_bench.log 2>&1
 cd $OLDPWD
 python tools/rocpd_summary.py --last 20 $OUT/prof_bench > $OUT/bench_kernel_trace_summary.txt 2>&1
 find $OUT/prof_bench -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
