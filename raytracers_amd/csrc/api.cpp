@@ -125,7 +125,7 @@ int get_uv(rt_context *ctx, int64_t w, int64_t h, const float **u, const float *
 struct Plan {
   int variant;
   int lds_nodes, lds_sph, smax, lmax, waves, grid;
-  int capb, capl;
+  int capb, capl, ray_planes;
   size_t lds_bytes;
 };
 
@@ -159,20 +159,30 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   // scene prefix, so: a configured shape is tried first; otherwise the shape with the most waves per
   // CU in which the WHOLE scene still fits in LDS, and for scenes that cannot fit the shape list in
   // the order measured best for them.  When nothing fits AUTO renders with the pixel kernel (no LDS).
-  struct Shape { int wgs, waves; };
+  // (pooled family: a shape also says whether the wave's ray table keeps the {d} plane -- 1 KB per wave that
+  // lets LEAF read the direction with one ds_read_b128 instead of three ds_bpermute; dropping it is what fits
+  // 16 waves next to the whole rgbbox scene)
+  struct Shape { int wgs, waves, planes; };
   std::vector<Shape> shapes;
+  const int pl_cfg = ctx->ray_planes == 2 || ctx->ray_planes == 3 ? ctx->ray_planes : 0;
+  auto add = [&](int wgs, int waves) {
+    if (!pooled) { shapes.push_back({wgs, waves, 0}); return; }
+    if (pl_cfg != 2) shapes.push_back({wgs, waves, 3});
+    if (pl_cfg != 3) shapes.push_back({wgs, waves, 2});
+  };
   if (force_waves) {
-    shapes = {{std::max(1, ctx->wgs_per_cu), force_waves}, {1, force_waves}};
+    add(std::max(1, ctx->wgs_per_cu), force_waves);
+    add(1, force_waves);
   } else {
-    if (ctx->waves_per_wg > 0) shapes.push_back({std::max(1, ctx->wgs_per_cu), ctx->waves_per_wg});
-    if (pooled) for (const Shape &sh : {Shape{1, 16}, Shape{1, 12}, Shape{1, 8}, Shape{1, 4}}) shapes.push_back(sh);
-    else for (const Shape &sh : {Shape{2, 8}, Shape{1, 8}, Shape{1, 4}}) shapes.push_back(sh);
+    if (ctx->waves_per_wg > 0) add(std::max(1, ctx->wgs_per_cu), ctx->waves_per_wg);
+    if (pooled) for (int waves : {16, 12, 8, 4}) add(1, waves);
+    else for (const auto &sh : {std::pair<int, int>{2, 8}, {1, 8}, {1, 4}}) add(sh.first, sh.second);
   }
   const int node_bytes = pooled ? 64 : 32;
   const int64_t scene_bytes = static_cast<int64_t>(ni) * node_bytes + static_cast<int64_t>(n) * 16;
   auto budget_of = [&](const Shape &sh) {
     const int total = std::min(ctx->lds_bytes, 160 * 1024) / sh.wgs;
-    const int scratch = pooled ? sh.waves * (rtk::kPooledWaveFixedDw + pl->capb + pl->capl) * 4
+    const int scratch = pooled ? sh.waves * rtk::pooled_wave_dw(sh.planes, pl->capb, pl->capl) * 4
                                : sh.waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
     return total - scratch - 512;
   };
@@ -191,6 +201,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   }
   const int wgs = shapes[static_cast<size_t>(pick)].wgs;
   pl->waves = shapes[static_cast<size_t>(pick)].waves;
+  pl->ray_planes = shapes[static_cast<size_t>(pick)].planes;
   int budget = budget_of(shapes[static_cast<size_t>(pick)]);
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   int ln, ls;
@@ -203,7 +214,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   }
   pl->lds_nodes = ln;
   pl->lds_sph = ls;
-  pl->lds_bytes = pooled ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->waves)
+  pl->lds_bytes = pooled ? rtk::pooled_lds_bytes(ln, ls, pl->capb, pl->capl, pl->ray_planes, pl->waves)
                          : rtk::persistent_lds_bytes(ln, ls, pl->smax, pl->lmax, pl->waves);
   // launch size: every persistent workgroup, except that a scene which is only partly LDS resident
   // renders frames up to ~1000x1000 faster with half of them (fuller waves, less L2 traffic in flight)
@@ -262,7 +273,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
-  p.capb = pl.capb; p.capl = pl.capl;
+  p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   if (pl.variant == RT_VARIANT_POOLED) {
@@ -464,6 +475,9 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->gpu_build = v != 0;
   } else if (k == "adaptive_order") {
     ctx->adaptive_order = v;
+  } else if (k == "ray_planes") {
+    if (v != 0 && v != 2 && v != 3) return fail(ctx, "ray_planes must be 0 (auto), 2 or 3");
+    ctx->ray_planes = v;
   } else if (k == "deep_class") {
     ctx->deep_class = std::min(8, std::max(0, v));
   } else {
@@ -793,7 +807,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
-  p.capb = pl.capb; p.capl = pl.capl;
+  p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   hipError_t e = hipSuccess;

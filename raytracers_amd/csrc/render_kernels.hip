@@ -321,6 +321,10 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // ---------------------------------------------------------------------------------
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
+__device__ __forceinline__ float pull(int lane_byte, float v) {   // v of the lane at byte address lane_byte (ds_bpermute)
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
+}
+
 // Work items are one dword: (reference << 8) | (slot * 4); `reference` is an inner node index
 // (box stack) or ~leaf index (leaf list), both < 2^23.
 //
@@ -333,14 +337,14 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   const int wave = threadIdx.x >> 6;
   const int plane = p.lds_nodes;          // float4 per node plane
   const int sph_base = 4 * plane;
-  // per-wave region: rays[3][64] float4 | key[64] (u64) | cnt[64] | dump[4] | box stack[capb] | leaf list[capl]
-  const int per_wave_dw = kPooledWaveFixedDw + p.capb + p.capl;
+  // per-wave region: key[64] (u64) | cnt[64] | dump[4] | rays[ray_planes][64] float4 | box stack[capb] | leaf list[capl]
+  const int per_wave_dw = pooled_wave_dw(p.ray_planes, p.capb, p.capl);
   unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
-  float4 *const wray = reinterpret_cast<float4 *>(wbase);     // [0..63] {o.xyz, a}  [64..127] {1/d, 0}  [128..191] {d, 0}
-  unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase + 768);
-  int *const wcnt = reinterpret_cast<int *>(wbase + 896);
-  unsigned *const wdump = wbase + 960;    // where lanes with nothing to append write
-  unsigned *const wbox = wbase + 964;
+  unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
+  int *const wcnt = reinterpret_cast<int *>(wbase + 128);
+  unsigned *const wdump = wbase + 192;    // where lanes with nothing to append write
+  float4 *const wray = reinterpret_cast<float4 *>(wbase + kPooledWaveFixedDw);   // [0..63] {o.xyz, a}  [64..127] {1/d, 0}  ([128..191] {d, 0})
+  unsigned *const wbox = wbase + kPooledWaveFixedDw + 256 * p.ray_planes;
   unsigned *const wleaf = wbox + p.capb;
   const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             wcnt[lane] = root_hit ? 1 : 0;    // 0: the fold is already complete (a miss), shaded next time
             wray[lane] = make_float4(r.ox, r.oy, r.oz, r.a);
             wray[64 + lane] = make_float4(r.ix, r.iy, r.iz, 0.0f);
-            wray[128 + lane] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+            if (p.ray_planes == 3) wray[128 + lane] = make_float4(r.dx, r.dy, r.dz, 0.0f);
             if (STATS) { n_rays++; n_box++; }
           }
           const unsigned long long m_root = bal(root_hit);
@@ -541,11 +545,17 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       nleaf = uni(nleaf > 64 ? nleaf - 64 : 0);
       const int sl = (int)(item & 0xfcu) >> 2;
       const int j = ~((int)item >> 8);        // stale zero entry -> ~0 = -1: masked below
-      const float4 ra = wray[sl], rd = wray[128 + sl];
-      asm volatile("" ::"v"(rd.w));           // keep both as 16-byte reads (ds_read_b96 is slower)
+      const float4 ra = wray[sl];
       Ray q;
       q.ox = ra.x; q.oy = ra.y; q.oz = ra.z; q.a = ra.w;
-      q.dx = rd.x; q.dy = rd.y; q.dz = rd.z;
+      if (p.ray_planes == 3) {                // wave-uniform
+        const float4 rd = wray[128 + sl];
+        asm volatile("" ::"v"(rd.w));         // keep it a 16-byte read (ds_read_b96 is slower)
+        q.dx = rd.x; q.dy = rd.y; q.dz = rd.z;
+      } else {                                // the direction straight from the owning lane's registers
+        const int sl4 = (int)(item & 0xfcu);
+        q.dx = pull(sl4, r.dx); q.dy = pull(sl4, r.dy); q.dz = pull(sl4, r.dz);
+      }
       const int jj = act ? j : 0;
       float4 s;
       if (ALL_LDS) {
@@ -793,13 +803,13 @@ hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_p
   }
 }
 
-size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg) {
-  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * (kPooledWaveFixedDw + capb + capl) * sizeof(unsigned);
+size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_planes, int waves_per_wg) {
+  return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
 template <int THREADS, bool ALL_LDS, bool STATS>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
-  const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, THREADS / 64);
+  const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
   auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);

@@ -8,9 +8,10 @@
 namespace rtk {
 
 constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>= any LBVH height)
-// pooled_kernel: fixed part of a wave's LDS region in dwords: ray table 3 x 64 float4, hit keys
-// 64 x u64, counters 64, dump 4 (then the box stack and the leaf list)
-constexpr int kPooledWaveFixedDw = 768 + 128 + 64 + 4;
+// pooled_kernel: a wave's LDS region in dwords: hit keys 64 x u64, counters 64, dump 4, then the ray
+// table (ray_planes x 64 float4), the box stack and the leaf list
+constexpr int kPooledWaveFixedDw = 128 + 64 + 4;
+constexpr int pooled_wave_dw(int ray_planes, int capb, int capl) { return kPooledWaveFixedDw + 256 * ray_planes + capb + capl; }
 
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)
@@ -41,6 +42,7 @@ struct KParams {
   int thr_shade, thr_leaf;   // phase-vote thresholds (lanes)
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
+  int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int low_box, thr_shade_low, low_leaf;   // policy while the box stack is short (see pooled_kernel)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
@@ -55,7 +57,7 @@ hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream);
 hipError_t launch_persistent(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
 size_t persistent_lds_bytes(int lds_nodes, int lds_sph, int smax, int lmax, int waves_per_wg);
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream);
-size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int waves_per_wg);
+size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_planes, int waves_per_wg);
 // prepare_scene on the GPU (bvh_build.hip).  Canonical {L, I} arrays + the traversal copy.
 struct GpuBvhOut {
   float *L7;                 // [n][7]
