@@ -11,12 +11,15 @@ frame is cut into cyclic 8-row tiles across the ranks (strong scaling: total wor
 the framebuffers of a step are gathered to rank 0 over RCCL inside the timed region (ONE
 gather per step: a rank's rows of both frames travel in one send buffer).
 
-Steps are independent frames, so up to --frames-in-flight of them (never more than K) are
-enqueued on separate HIP streams, each with its own context and framebuffers.  All K steps
-complete inside the barrier/synchronize bracket.  `value` is that overlapped throughput; the
-reference's own protocol -- one render + sync at a time (futhark/main.c:107-124) -- is reported
-next to it as `serial_value` / `serial_ms_per_frame`, and the >= 10x-MI100 target check
-(`targets`) is quoted on the serial figures.
+Steps are independent frames, so the K timed steps are handed to the library's throughput entry,
+rt_render_batch: ONE launch per scene renders that scene's frame of all K steps (on N > 1 GPUs: two
+chunks of K/2 steps, so that the first chunk's gather overlaps the second chunk's rendering) -- the
+persistent waves run straight across frame boundaries and the launch's fill and drain are paid once.
+All K steps complete inside the barrier/synchronize bracket.  (--protocol lanes is the round-1
+protocol: one launch per frame, up to --frames-in-flight steps overlapped on separate HIP streams.)
+`value` is that throughput; the reference's own protocol -- one render + sync at a time
+(futhark/main.c:107-124) -- is reported next to it as `serial_value` / `serial_ms_per_frame`, and the
+>= 10x-MI100 target check (`targets`) is quoted on the serial figures.
 
 Every timed launch is VERIFIED: the framebuffers are poisoned before the timed region and,
 after its closing fence, the images of every lane are checksummed on the device
@@ -185,9 +188,9 @@ class Checksummer:
         return int(v.sum().item()) & 0xffffffff
 
 
-def roofline_block(frames, world, variant, grid_div, steps, elapsed, per_scene, work):
+def roofline_block(frames, world, variant, key, steps, elapsed, per_scene, work):
     """VALU-issue roofline (+ LDS, HBM side figures) from profiles/pmc.json and profiles/issue_peak.json."""
-    alg = sum(per_scene[k]["alg_bytes_per_launch"] for k in per_scene) * steps / elapsed / 1e9
+    alg = sum(per_scene[k]["alg_bytes_per_frame"] for k in per_scene) * steps / elapsed / 1e9   # (per frame x steps)
     rf = {"bound": "valu_issue", "kernel": "pooled_kernel (the launches of " + " and ".join(f"{s} {w}x{h}" for s, h, w in frames) + ")",
           "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": None}
     try:
@@ -204,7 +207,6 @@ def roofline_block(frames, world, variant, grid_div, steps, elapsed, per_scene, 
             rf["note"] = ("profiles/pmc.json was measured on other kernel sources (hash mismatch): refused; "
                           "rerun tools/gpu_round.sh and commit its pmc.json")
         elif variant in (0, 3):
-            key = f"grid_div={grid_div}"
             ents = [pmc.get("launches", {}).get(f"{s} {w}x{h}", {}).get(key) for s, h, w in frames]
             if all(ents):
                 peak = float(ip["valu_peak_G"])
@@ -247,6 +249,9 @@ def main():
     ap.add_argument("--workload", default="rgbbox+irreg-1000", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0 auto (pooled), 1 pixel, 2 persistent, 3 pooled")
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
+    ap.add_argument("--protocol", choices=["batch", "lanes"], default="batch",
+                    help="batch: one rt_render_batch launch per scene and chunk; lanes: one launch per frame, frames overlapped on streams")
+    ap.add_argument("--chunks", type=int, default=0, help="batch protocol: launches per scene (0: 1 on one GPU, 2 on several)")
     ap.add_argument("--frames-in-flight", type=int, default=10, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
@@ -285,34 +290,44 @@ def main():
 
     frames = WORKLOADS[args.workload]
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
-    # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).  Ten lanes at
-    # a quarter-size launch each were the best of {6, 10, 20} x grid_div {2, 4, 8} at the driver's K = 20
-    # (gpurun_out sweep): a workgroup fills a CU's LDS, so only 4 quarter-size launches are resident at a
-    # time and more lanes only lengthen the queue -- and the drain at the end of the bracket.
-    S = max(1, min(args.frames_in_flight, args.steps))
-    # With many frames in flight a launch need not fill the machine by itself: a quarter of the
-    # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is
-    # hidden by the other frames.  One frame at a time keeps the library default.
-    opts_pipe = dict(opts)
-    if S >= 4 and args.variant in (0, 3):
-        opts_pipe.setdefault("grid_div", 4)
-        # dedicated waves for the deepest tiles shorten ONE frame's tail, which overlapped frames
-        # hide anyway; they cost 2-3 % of throughput here
-        opts_pipe.setdefault("deep_class", 0)
-    # one "lane" per frame in flight: its own HIP stream, contexts, prepared scenes, framebuffers
+    batch = args.protocol == "batch" and args.variant in (0, 3)
+    if batch:
+        # K steps in C launches per scene (C = 1 on one GPU; 2 on several, so that a chunk's gather overlaps the next chunk's
+        # rendering); library-default knobs: a batch launch uses every persistent workgroup and no dedicated deep-tile waves
+        C = max(1, min(args.chunks or (1 if world == 1 else 2), args.steps))
+        chunk_sizes = [args.steps // C + (1 if i < args.steps % C else 0) for i in range(C)]
+        S = C
+        opts_pipe = dict(opts)
+    else:
+        # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).  Ten lanes at
+        # a quarter-size launch each were the best of {6, 10, 20} x grid_div {2, 4, 8} at the driver's K = 20
+        # (DESIGN.md 6): a workgroup fills a CU's LDS, so only 4 quarter-size launches are resident at a time and more
+        # lanes only lengthen the queue -- and the drain at the end of the bracket.
+        S = max(1, min(args.frames_in_flight, args.steps))
+        chunk_sizes = [1] * S
+        # With many frames in flight a launch need not fill the machine by itself: a quarter of the
+        # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is
+        # hidden by the other frames.  One frame at a time keeps the library default.
+        opts_pipe = dict(opts)
+        if S >= 4 and args.variant in (0, 3):
+            opts_pipe.setdefault("grid_div", 4)
+            # dedicated waves for the deepest tiles shorten ONE frame's tail, which overlapped frames
+            # hide anyway; they cost 2-3 % of throughput here
+            opts_pipe.setdefault("deep_class", 0)
+    # one "lane" per launch in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
 
     class Lane:
-        """the renderers of one frame in flight + the step (render all, one gather, assemble)"""
-        def __init__(self, o, fr=frames):
+        """the renderers of one launch in flight + the step (render all, one gather, assemble)"""
+        def __init__(self, o, fr=frames, nbatch=1):
             self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in fr]
-            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device)
+            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch)
 
     lanes = []
-    for st in streams:
+    for st, nb in zip(streams, chunk_sizes):
         with torch.cuda.stream(st):
-            lanes.append(Lane(opts_pipe))
-    serial_lane = Lane(opts) if (S > 1 and not args.no_serial_extra) else None   # on the default stream
+            lanes.append(Lane(opts_pipe, nbatch=nb))
+    serial_lane = Lane(opts) if ((S > 1 or batch) and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
     renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, lanes[0].prs)]
 
@@ -351,30 +366,34 @@ def main():
     cks = Checksummer(device)
 
     def verify(which, fr, what):
-        """rank 0: every lane's images against the oracle's checksums"""
+        """rank 0: every image of every lane (a batch lane holds nbatch of them per scene) against the oracle's checksums"""
         bad = []
         n = 0
         if rank == 0:
             for li, ln in enumerate(which):
-                for (scene, h, w), img in zip(fr, ln.step.images):
+                for (scene, h, w), imgs in zip(fr, ln.step.images):
                     want = FRAME_CHECKSUM.get((scene, h, w))
                     if want is None:
                         continue
-                    got = cks(img)
-                    n += 1
-                    if got != want:
-                        bad.append(f"{what} lane {li} {scene} {w}x{h}: checksum {got:08x}, oracle {want:08x}")
+                    for fi, img in enumerate(imgs if imgs.dim() == 3 else [imgs]):
+                        got = cks(img)
+                        n += 1
+                        if got != want:
+                            bad.append(f"{what} launch {li} frame {fi} {scene} {w}x{h}: checksum {got:08x}, oracle {want:08x}")
         if bad:
             raise SystemExit("VERIFICATION FAILED (pixels differ from the oracle's):\n  " + "\n  ".join(bad))
         return n
 
     def timed(nsteps, nlanes):
+        """K steps inside one bracket.  lanes protocol: nsteps launches of every scene, round-robin over the lanes;
+        batch protocol: every lane's launches once (together they cover exactly K steps); nlanes == 0: the serial lane"""
         every = max(1, args.event_every)
+        nlaunch = S if (batch and nlanes != 0) else nsteps
         ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
-              if k % every == 0 else None for k in range(nsteps)]
+              if k % every == 0 else None for k in range(nlaunch)]
         fence()
         t0 = time.perf_counter()
-        for k in range(nsteps):
+        for k in range(nlaunch):
             step(k, ev[k], nlanes)
         fence()
         dt = time.perf_counter() - t0
@@ -383,7 +402,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         # per-launch durations on this rank: events recorded on the stream each kernel is launched on
-        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nsteps) if ev[k] is not None]))
+        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nlaunch) if ev[k] is not None]))
                for i in range(len(frames))]
         return dt, kms
 
@@ -392,12 +411,12 @@ def main():
     # untimed warm-up steps, then exactly K timed steps.
     for k in range(2 * S):
         step(k)
-    for k in range(args.warmup):
+    for k in range(S if (batch and args.warmup > 0) else args.warmup):   # (batch: one more pass of all K >= W steps)
         step(k)
     torch.cuda.synchronize()
     poison(lanes)
     elapsed, kern_ms = timed(args.steps, S)
-    n_verified = verify(lanes[:min(S, args.steps)], frames, "timed region,")
+    n_verified = verify(lanes, frames, "timed region,")
     serial = None
     if serial_lane is not None:
         for k in range(3):
@@ -450,10 +469,11 @@ def main():
         for i, (scene, h, w, _) in enumerate(renderers):
             r, b, s = work[(scene, h, w)]
             ba = bytes_alg(b, s, h, w) / world        # this rank's share of the frame (cyclic tiles)
+            fpl = max(chunk_sizes) if batch else 1
             per_scene[f"{scene}_{w}x{h}"] = {
-                "rays": r, "kernel_ms": kern_ms[i], "Mray_s_kernel": r / world / (kern_ms[i] * 1e-3) / 1e6,
-                "alg_bytes_per_launch": ba}
-        inflight = sum(kern_ms) * args.steps / (elapsed * 1e3)
+                "rays": r, "kernel_ms": kern_ms[i], "frames_per_launch": fpl,
+                "Mray_s_kernel": r * fpl / world / (kern_ms[i] * 1e-3) / 1e6, "alg_bytes_per_frame": ba}
+        inflight = sum(kern_ms) * (S if batch else args.steps) / (elapsed * 1e3)
         out = {
             "metric": "Mray/s (primary+secondary) on rgbbox & irreg 1000x1000" if args.workload == "rgbbox+irreg-1000"
                       else f"Mray/s (primary+secondary) on {args.workload}",
@@ -461,11 +481,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "verified": True, "verified_images": n_verified,
-            "value_protocol": f"overlapped throughput: {S} independent frames in flight on {S} HIP streams, all {args.steps} steps inside "
-                              "the timed bracket; the reference's protocol (one render + sync at a time) is serial_value",
+            "value_protocol": (f"batched throughput: the {args.steps} steps' frames of each scene in {S} rt_render_batch launch(es) of "
+                               f"{'/'.join(str(c) for c in chunk_sizes)} frames, all inside the timed bracket" if batch else
+                               f"overlapped throughput: {S} independent frames in flight on {S} HIP streams, all {args.steps} steps inside "
+                               "the timed bracket") + "; the reference's protocol (one render + sync at a time) is serial_value",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
-                       "options": opts_pipe, "frames_in_flight": S,
+                       "options": opts_pipe, "protocol": args.protocol if batch or args.protocol == "lanes" else "lanes",
+                       "launches_in_flight": S, "frames_per_launch": chunk_sizes,
                        "partition": f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per step"
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
             "per_scene": per_scene,
@@ -476,7 +499,8 @@ def main():
             "derived_reference": {"futhark_mi100_Mray_s": {"rgbbox": 287.3, "irreg": 216.1},
                                   "note": "README.md:50 render times / oracle ray counts; different hardware; compare with serial_*"},
         }
-        out["roofline"] = roofline_block(frames, world, args.variant, opts_pipe.get("grid_div", 0), args.steps, elapsed, per_scene, work)
+        out["roofline"] = roofline_block(frames, world, args.variant, "batch" if batch else f"grid_div={opts_pipe.get('grid_div', 0)}",
+                                         args.steps, elapsed, per_scene, work)
         out["roofline"]["per_launch"] = {
             "kernel_ms": {k: per_scene[k]["kernel_ms"] for k in per_scene}, "avg_launches_in_flight": inflight,
             "note": "HIP events around each launch on its own stream inside the timed region; launches in flight stretch one another"}

@@ -108,6 +108,13 @@ int rt_render_part(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
  * prepared` does in the reference (ray.fut:246): the aspect ratio stays the one prepare_scene was given. */
 int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int64_t height, const float cam12[12],
                     int32_t max_depth, int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev);
+/* Throughput entry: `nframes` frames of one prepared scene in ONE launch (a camera path, or the same view again and
+ * again as the reference's harness does, main.c:107-124).  Frame f is traced through cams12 + 12 f (host memory; NULL:
+ * the prepared camera for every frame) into out_dev + f * frame_stride (int32 elements, >= rows * w).  The persistent
+ * waves run straight across frame boundaries, so a launch's fill and drain are paid once per batch instead of once
+ * per frame.  Partition arguments as rt_render_part; not available on a multi-device context. */
+int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                    int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride, int32_t *out_dev);
 int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);
 /* Scatter one part's packed rows into a full h*w image on the device (rank-0 side of
  * the framebuffer gather). */

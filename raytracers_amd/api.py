@@ -241,6 +241,22 @@ def render_into(out_ptr, h, w, prepared, max_depth=MAX_DEPTH, part=0, nparts=1, 
                                        int(rows_per_tile), int(part), int(nparts), C.c_void_p(out_ptr)))
 
 
+def render_batch_into(out_ptr, h, w, prepared, nframes, frame_stride=None, cams=None, max_depth=MAX_DEPTH, part=0, nparts=1,
+                      rows_per_tile=ROWS_PER_TILE):
+    """`nframes` frames in ONE launch (rt_render_batch): frame f -> out_ptr + 4 * f * frame_stride (default: packed,
+    part_rows * w elements apart), traced through cams[f] (nframes x 12 floats) or, cams=None, the prepared camera."""
+    ctx = prepared.ctx
+    if frame_stride is None:
+        frame_stride = part_rows(h, part, nparts, rows_per_tile) * w
+    cp = None
+    if cams is not None:
+        c = np.ascontiguousarray(cams, dtype=np.float32)
+        assert c.size == 12 * nframes
+        cp = c.ctypes.data
+    ctx._check(lib.rt_render_batch(ctx._h, prepared._h, int(h), int(w), int(max_depth), int(rows_per_tile), int(part), int(nparts),
+                                   int(nframes), C.c_void_p(cp), int(frame_stride), C.c_void_p(out_ptr)))
+
+
 def render(h, w, prepared, max_depth=MAX_DEPTH):
     """entry render h w prepared (ray.fut:246): returns the [h][w]i32 image as a numpy array."""
     buf = prepared.ctx.alloc_i32(h * w)

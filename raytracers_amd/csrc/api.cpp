@@ -230,7 +230,8 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
 }  // namespace
 
 int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
-                        int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12) {
+                        int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12, int32_t nframes,
+                        int64_t frame_stride, const float *cams_dev) {
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
   if (!out_dev) return fail(ctx, "null output pointer");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30))
@@ -254,19 +255,42 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.max_depth = max_depth;
   p.out = out_dev;
   p.stats = ctx->stats_dev;
+  p.nframes = 1;
   if (p.rows_local == 0) return 0;
+  if (nframes < 1 || (nframes > 1 && (frame_stride < static_cast<int64_t>(p.rows_local) * p.w ||
+                                     frame_stride * nframes >= (int64_t(1) << 31))))
+    return fail(ctx, "bad batch: nframes >= 1, frame_stride >= rows * w, nframes * frame_stride < 2^31");
   if (max_depth == 0) {
     // `while depth < 0`: no ray is traced, every pixel is the initial colour (0,0,0)
-    RT_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(int32_t) * static_cast<size_t>(p.rows_local) * p.w, ctx->stream));
+    for (int f = 0; f < nframes; ++f)
+      RT_HIP(ctx, hipMemsetAsync(out_dev + f * frame_stride, 0, sizeof(int32_t) * static_cast<size_t>(p.rows_local) * p.w, ctx->stream));
     return 0;
   }
   Plan pl{};
   if (stats) pl.variant = RT_VARIANT_PIXEL;
-  else if (int rc = make_plan(ctx, ps, &pl, static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8))) return rc;
+  else if (int rc = make_plan(ctx, ps, &pl, static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8) * nframes)) return rc;
+  if (nframes > 1 && pl.variant != RT_VARIANT_POOLED) {
+    // only the pooled family renders a batch in one launch: the others take the frames one by one
+    std::vector<float> hc;
+    if (cams_dev) {
+      hc.resize(static_cast<size_t>(nframes) * 12);
+      RT_HIP(ctx, hipMemcpyAsync(hc.data(), cams_dev, hc.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int f = 0; f < nframes; ++f)
+      if (int rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev + f * frame_stride, stats,
+                                  cams_dev ? hc.data() + 12 * f : cam12))
+        return rc;
+    return 0;
+  }
   if (pl.variant == RT_VARIANT_PIXEL) {
     RT_HIP(ctx, rtk::launch_pixel(p, stats, ctx->stream));
     return 0;
   }
+  p.nframes = nframes;
+  p.tpt_log2 = nframes > 1 ? 2 : 0;
+  p.frame_stride = static_cast<int>(frame_stride);
+  p.cams = reinterpret_cast<const rtk::Cam *>(cams_dev);
   p.queue = ctx->queue_dev;
   p.queue_base = ctx->queue_base;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
@@ -281,7 +305,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
     TileOrder *to = nullptr;
-    if (ctx->adaptive_order) {
+    if (ctx->adaptive_order && !p.cams) {   // (a batch with its own cameras has no single view to order tiles by)
       for (auto &o : ps->orders)
         if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
             o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks)
@@ -319,7 +343,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
-  ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(pl.grid) * pl.waves;
+  // every wave stops at its first out-of-range ticket: tickets drawn = ceil(tiles / tiles per ticket) + waves
+  const unsigned tiles_total = static_cast<unsigned>(p.nchunks) * static_cast<unsigned>(p.nframes);
+  ctx->queue_base += ((tiles_total + (1u << p.tpt_log2) - 1) >> p.tpt_log2) + static_cast<unsigned>(pl.grid) * pl.waves;
   return 0;
 }
 using rti::enqueue_render;
@@ -386,6 +412,7 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
     (void)hipFree(t.u);
     (void)hipFree(t.v);
   }
+  if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
@@ -708,6 +735,34 @@ extern "C" int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t
   return render_entry(ctx, objs, height, width, max_depth, rows_per_tile, part, nparts, out_dev, cam12);
 }
 
+// N frames of one prepared scene in ONE launch of the pooled kernel (its ticket queue simply runs over the tiles of
+// all frames, so the waves stay full across frame boundaries and the launch's fill and drain are paid once).
+extern "C" int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                               int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
+                               int32_t *out_dev) {
+  if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
+  if (ctx->group) return fail(ctx, "rt_render_batch: not on a multi-device context");
+  if (nframes < 1 || nframes > 4096) return fail(ctx, "rt_render_batch: 1 .. 4096 frames");
+  const float *cams_dev = nullptr;
+  if (cams12) {
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(float) * 12 * static_cast<size_t>(nframes);
+    if (bytes > ctx->cams_bytes) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
+      ctx->cams_dev = nullptr;
+      ctx->cams_bytes = 0;
+      RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cams_dev), bytes));
+      ctx->cams_bytes = bytes;
+    }
+    // (stream-ordered: a previous batch still reading the buffer finishes first; the source is copied before return
+    // when it is pageable host memory)
+    RT_HIP(ctx, hipMemcpyAsync(ctx->cams_dev, cams12, bytes, hipMemcpyHostToDevice, ctx->stream));
+    cams_dev = ctx->cams_dev;
+  }
+  return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false, nullptr, nframes, frame_stride, cams_dev);
+}
+
 extern "C" int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts) {
   return rt::part_rows(h, rows_per_tile, part, nparts);
 }
@@ -800,6 +855,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.tiles_x = (p.w + 7) / 8;
   p.max_depth = max_depth;
   p.out = tmp;
+  p.nframes = 1;
   p.stats = ctx->stats_dev;
   p.trace = trace;
   p.queue = ctx->queue_dev; p.queue_base = ctx->queue_base;

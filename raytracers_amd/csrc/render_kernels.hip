@@ -319,6 +319,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
 // 64 items per "generation" with strictly increasing depth labels => size <= 64*H + 128.
 // The leaf list is drained first whenever it holds >= 64 items => size <= 63 + 128.
 // ---------------------------------------------------------------------------------
+constexpr int kOrderClasses = 8;   // cost classes of the adaptive tile order (tile_order_kernel)
 constexpr unsigned long long kKeyInit = ((unsigned long long)0x4e6e6b28u << 32) | 0xffffffffull;   // (1e9, no leaf)
 
 __device__ __forceinline__ float pull(int lane_byte, float v) {   // v of the lane at byte address lane_byte (ds_bpermute)
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   unsigned q_next = 0, q_end = 0;
   int q_tile = 0;          // tile the current ticket maps to
   int q_col0 = 0, q_row0 = 0;   // its first pixel column / local row
+  int q_frame_off = 0;     // batch launch: first pixel of the ticket's frame in p.out
+  Cam q_cam = p.cam;       // ... and that frame's camera
   int ptile = 0;           // (per lane) tile of the pixel in this slot, for the cost record
   bool exhausted = false;
   // A wave that draws a DEEP tile (one whose longest bounce chain was long in the recorded frame)
@@ -463,38 +466,67 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           while (m != 0ull) {            // wave-uniform loop
             if (q_next == q_end) {
               if (hold) break;           // a deep tile is in flight: no further tickets for now
+              // one ticket = 1 << tpt_log2 consecutive tiles (a batch launch draws four at a time: 4096 waves on one
+              // counter otherwise saturate it -- ~90 atomics per microsecond -- before they saturate the chip)
               unsigned t = 0;
               if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
               t = __builtin_amdgcn_readfirstlane(t);
-              if (t >= (unsigned)p.nchunks) {
+              const unsigned total = (unsigned)p.nchunks * (unsigned)p.nframes;
+              const unsigned first = t << p.tpt_log2;
+              if (first >= total) {
                 exhausted = true;
                 if (STATS) tr_exh = wall_clock64();
                 break;
               }
-              q_next = t * 64u;
-              q_end = q_next + 64u;
+              const unsigned last = first + (1u << p.tpt_log2);
+              q_next = first * 64u;
+              q_end = (last < total ? last : total) * 64u;
+            }
+            if ((q_next & 63u) == 0u) {
+              // entering a tile: where it is.  A batch launch hands out the tiles of frame 0, then of frame 1, ...:
+              // frame f's pixels go to out + f * frame_stride and (when the batch carries cameras) through cams[f]
+              unsigned t = q_next >> 6;
+              if (p.nframes > 1) {
+                unsigned f;
+                if (p.order != nullptr) {
+                  // one view, ordered tiles: CLASS-major over the batch -- every frame's tiles of the most expensive
+                  // class (longest bounce chains) first, so the last frame's chains do not start last
+                  const int *cb = p.order + p.nchunks;   // first ticket of each cost class, then the tile count
+                  unsigned c = 0;
+                  while (c + 1 < (unsigned)kOrderClasses && t >= (unsigned)p.nframes * (unsigned)cb[c + 1]) ++c;
+                  const unsigned base = (unsigned)cb[c], size = (unsigned)cb[c + 1] - base;
+                  const unsigned within = t - (unsigned)p.nframes * base;
+                  f = within / size;
+                  t = base + (within - f * size);
+                } else {
+                  f = t / (unsigned)p.nchunks;
+                  t -= f * (unsigned)p.nchunks;
+                }
+                q_frame_off = (int)(f * (unsigned)p.frame_stride);
+                if (p.cams != nullptr) q_cam = p.cams[f];
+              }
               q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
-              if (p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
+              if (p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
                 hold = true;
                 __builtin_amdgcn_s_setprio(3);
               }
-              const int ty = q_tile / p.tiles_x;                    // once per ticket, scalar
+              const int ty = q_tile / p.tiles_x;                    // once per tile, scalar
               q_col0 = (q_tile - ty * p.tiles_x) * 8;
               q_row0 = ty * 8;
             }
-            const unsigned avail = q_end - q_next;
+            const unsigned avail = 64u - (q_next & 63u);   // rest of the current tile
             const unsigned rank = (unsigned)lane_rank(m);
             const unsigned cnt = (unsigned)__popcll(m);
             if (want & (rank < avail)) {
               const int within = (int)((q_next + rank) & 63u);
               const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
               if (col < p.w && lrow < p.rows_local) {
-                slot = lrow * p.w + col;
+                slot = q_frame_off + lrow * p.w + col;
                 ptile = q_tile;
                 // cyclic row tiles with rows_per_tile = 1 << rpt_log2 (division-free global_row)
                 const int k = lrow >> p.rpt_log2;
                 const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
-                primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
+                primary_dir_uv(q_cam, p.u_tab[col], p.v_tab[grow], r);
                 want = false;
               }
             }
@@ -655,7 +687,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
 // the record.  It only permutes the order in which independent pixels are traced.
 // ---------------------------------------------------------------------------------
 constexpr int kOrderThreads = 1024;
-constexpr int kOrderClasses = 8;
 
 __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles) {
   __shared__ int hist[kOrderClasses][kOrderThreads];   // [class][thread], 32 KB

@@ -29,7 +29,11 @@ struct KParams {
   int rpt_log2;          // log2(rows_per_tile) when it is a power of two, else -1
   int tiles_x;           // ceil(w / 8)
   int max_depth;
-  int32_t *out;          // [rows_local * w]
+  int32_t *out;          // [rows_local * w]  (batch launch: frame f at out + f * frame_stride)
+  int nframes;           // pooled family: frames rendered by this one launch (>= 1)
+  int tpt_log2;          // pooled family: a ticket of the tile queue covers 1 << tpt_log2 consecutive tiles
+  int frame_stride;      // int32 elements between consecutive frames' buffers
+  const Cam *cams;       // [nframes] per-frame cameras (nullptr: `cam` for every frame)
   unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
   unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
   // persistent family

@@ -62,6 +62,8 @@ struct rt_context {
   // fit): the first prepare_scene then pays no hipMalloc either.
   char *arena = nullptr;
   std::vector<unsigned char> arena_used;   // one flag per granule
+  float *cams_dev = nullptr;   // rt_render_batch: the batch's cameras on the device
+  size_t cams_bytes = 0;
   rt_group *group = nullptr;   // multi-device context: the devices behind it (multi_gpu.cpp); this context is the first device's
   char *pinned = nullptr;  // host-pinned block the build kernels report through
   char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
@@ -113,7 +115,8 @@ int fail(rt_context *ctx, const std::string &msg);
 int hip_fail(rt_context *ctx, hipError_t e, const char *what);
 // Enqueue one part of a frame on ctx's stream (single device).  cam12 == nullptr: the prepared camera.
 int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
-                   int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr);
+                   int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr, int32_t nframes = 1,
+                   int64_t frame_stride = 0, const float *cams_dev = nullptr);
 // multi_gpu.cpp
 int group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,
                  const float *cam12);

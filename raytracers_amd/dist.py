@@ -54,6 +54,13 @@ class HipPartRenderer:
         api.render_into(out.data_ptr(), self.h, self.w, self.prepared, self.max_depth, part, nparts)
         return out
 
+    def batch(self, part, nparts, nbatch, out, frame_stride):
+        """`nbatch` frames of this rank's rows in ONE launch (rt_render_batch): frame f at out + f * frame_stride elements."""
+        assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.numel() >= nbatch * frame_stride
+        api.render_batch_into(out.data_ptr(), self.h, self.w, self.prepared, nbatch, frame_stride=frame_stride,
+                              max_depth=self.max_depth, part=part, nparts=nparts)
+        return out
+
     def place(self, part, nparts, part_tensor, image):
         api.place_part(self.ctx, self.h, self.w, part, nparts, part_tensor.data_ptr(), image.data_ptr())
 
@@ -71,23 +78,29 @@ class ShardedStep:
 
     frames: list of (part_renderer, h, w); part_renderer(part, nparts, out) must fill
     out[:part_rows] (out: [pad_rows, w] int32 on `device`) and may be asynchronous on the
-    device's current stream."""
+    device's current stream.
 
-    def __init__(self, frames, device, group=None, dst=0):
+    nbatch > 1: the step covers `nbatch` frames of EACH scene -- a renderer with a `.batch` method renders its
+    nbatch frames in one launch (rt_render_batch), the single gather carries all of them, and `images[i]` is
+    an [nbatch, h, w] tensor."""
+
+    def __init__(self, frames, device, group=None, dst=0, nbatch=1):
         self.frames = list(frames)
         self.group, self.dst = group, dst
+        self.nbatch = int(nbatch)
         self.device = torch.device(device)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pad_rows = [max_part_rows(h, self.world) for _, h, _ in self.frames]
-        sizes = [pr * w for pr, (_, _, w) in zip(self.pad_rows, self.frames)]
+        sizes = [self.nbatch * pr * w for pr, (_, _, w) in zip(self.pad_rows, self.frames)]
         self.offs = [int(o) for o in np.concatenate([[0], np.cumsum(sizes)])]   # int32 elements
         self.total = self.offs[-1]
         self.recv_all = None
         self.recv = None
         self.images = None
         if self.rank == dst:
-            self.images = [torch.empty((h, w), dtype=torch.int32, device=self.device) for _, h, w in self.frames]
+            self.images = [torch.empty((h, w) if self.nbatch == 1 else (self.nbatch, h, w), dtype=torch.int32, device=self.device)
+                           for _, h, w in self.frames]
         # A CPU-only backend (gloo) cannot move device memory: stage the gather through host
         # buffers then.  Only used to exercise the multi-rank control flow on a one-GPU box
         # (several ranks sharing cuda:0); the product path is backend "nccl" = RCCL over xGMI.
@@ -100,7 +113,7 @@ class ShardedStep:
             self.outs = self.images            # one part == the whole image: nothing to gather or assemble
         else:
             self.send = torch.zeros(self.total, dtype=torch.int32, device=self.device)
-            self.outs = [self.send[self.offs[i]:self.offs[i + 1]].view(self.pad_rows[i], w)
+            self.outs = [self.send[self.offs[i]:self.offs[i + 1]].view(self.nbatch * self.pad_rows[i], w)
                          for i, (_, _, w) in enumerate(self.frames)]
             if self.rank == dst:
                 # one contiguous buffer; gather_list entries are views of it so that a single
@@ -116,7 +129,14 @@ class ShardedStep:
         for i, (render_part, _, _) in enumerate(self.frames):
             if events is not None and events[i] is not None:
                 events[i][0].record()
-            render_part(self.rank, self.world, self.outs[i])
+            if self.nbatch == 1:
+                render_part(self.rank, self.world, self.outs[i])
+            elif hasattr(render_part, "batch"):
+                render_part.batch(self.rank, self.world, self.nbatch, self.outs[i], self.pad_rows[i] * self.frames[i][2])
+            else:
+                o = self.outs[i].view(self.nbatch, -1, self.frames[i][2])
+                for f in range(self.nbatch):
+                    render_part(self.rank, self.world, o[f])
             if events is not None and events[i] is not None:
                 events[i][1].record()
         if self.direct:
@@ -147,15 +167,18 @@ class ShardedStep:
 
     def _assemble(self, i):
         render_part, h, w = self.frames[i]
-        image, stacked = self.images[i], self.recv_all[:, self.offs[i]:self.offs[i + 1]]
-        if image.is_cuda and hasattr(render_part, "place_all"):
-            render_part.place_all(self.world, self.pad_rows[i], stacked, image, part_stride=self.total)
-            return
-        for p in range(self.world):
-            n = api.part_rows(h, p, self.world)
-            if n:
-                idx = torch.as_tensor(tile_rows(h, p, self.world), device=image.device)
-                image[idx] = stacked[p].view(self.pad_rows[i], w)[:n]
+        per = self.pad_rows[i] * w
+        for f in range(self.nbatch):
+            image = self.images[i] if self.nbatch == 1 else self.images[i][f]
+            stacked = self.recv_all[:, self.offs[i] + f * per:self.offs[i] + (f + 1) * per]
+            if image.is_cuda and hasattr(render_part, "place_all"):
+                render_part.place_all(self.world, self.pad_rows[i], stacked, image, part_stride=self.total)
+                continue
+            for p in range(self.world):
+                n = api.part_rows(h, p, self.world)
+                if n:
+                    idx = torch.as_tensor(tile_rows(h, p, self.world), device=image.device)
+                    image[idx] = stacked[p].view(self.pad_rows[i], w)[:n]
 
 
 class ShardedRenderer(ShardedStep):

@@ -68,14 +68,14 @@ def test_two_rank_gather_equals_single_render(scene, h, w):
     assert (img == full).all()
 
 
-def _step_worker(rank, world, port, frames, q):
+def _step_worker(rank, world, port, frames, q, nbatch=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from raytracers_amd.dist import ShardedStep
-        st = ShardedStep([(OraclePartRenderer(s, h, w), h, w) for s, h, w in frames], device="cpu")
+        st = ShardedStep([(OraclePartRenderer(s, h, w), h, w) for s, h, w in frames], device="cpu", nbatch=nbatch)
         imgs = st.render()
         imgs = st.render()   # buffers are reused across steps
         if rank == 0:
@@ -103,6 +103,26 @@ def test_one_gather_per_step_of_several_frames(world):
     for (scene, h, w), img in zip(frames, imgs):
         full, _ = O.OracleScene(scene).render(h, w)
         assert (img == full).all()
+
+
+def test_batched_step_three_frames_of_each_scene_in_one_gather():
+    """ShardedStep(nbatch=3): the gather carries three frames of each scene; images[i] is [3, h, w]."""
+    frames = [("rgbbox", 19, 24), ("irreg", 33, 16)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, frames, q, 3)) for r in range(2)]
+    for p in procs:
+        p.start()
+    imgs = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for (scene, h, w), img in zip(frames, imgs):
+        full, _ = O.OracleScene(scene).render(h, w)
+        assert img.shape == (3, h, w)
+        for f in range(3):
+            assert (img[f] == full).all()
 
 
 def test_single_rank_path_without_process_group():

@@ -569,6 +569,47 @@ def test_render_at_another_size_uses_the_prepared_camera(R, ctx):
     assert int((R.render(120, 160, ps) != want).sum()) == 0
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_batch_of_frames_in_one_launch(R, variant):
+    """rt_render_batch: N frames per launch, each equal to the frame rendered on its own -- the same view repeated (with
+    and without the adaptive tile order, padded frame stride), a camera path, and one part of a partition."""
+    import torch
+    ctx = R.Context()
+    ctx.set_variant(variant)
+    h, w, n = 120, 168, 5
+    ps = R.prepare_scene(h, w, ctx.rgbbox())
+    want, _ = _oracle("rgbbox").render(h, w)
+    stride = h * w + 40
+    for rep in range(3):
+        out = torch.full((n, stride), -7, dtype=torch.int32, device="cuda")
+        R.render_batch_into(out.data_ptr(), h, w, ps, n, frame_stride=stride)
+        ctx.sync()
+        got = out.cpu().numpy()
+        for f in range(n):
+            assert int((got[f, :h * w].reshape(h, w) != want).sum()) == 0, (rep, f)
+        assert (got[:, h * w:] == -7).all()
+    # a camera path: frame f through its own camera == render_image with that camera
+    base = ps.camera()
+    cams = np.stack([base + np.float32(0.37 * f) * np.array([1, 0, 0] * 1 + [0] * 9, np.float32) for f in range(n)])
+    out = torch.zeros((n, h * w), dtype=torch.int32, device="cuda")
+    R.render_batch_into(out.data_ptr(), h, w, ps, n, cams=cams)
+    ctx.sync()
+    got = out.cpu().numpy()
+    for f in range(n):
+        assert int((got[f].reshape(h, w) != R.render_image(ps, w, h, cams[f])).sum()) == 0, f
+    # part 1 of 3 of every frame
+    rows = R.part_rows(h, 1, 3)
+    out = torch.zeros((n, rows * w), dtype=torch.int32, device="cuda")
+    R.render_batch_into(out.data_ptr(), h, w, ps, n, part=1, nparts=3)
+    one = torch.zeros((rows, w), dtype=torch.int32, device="cuda")
+    R.render_into(one.data_ptr(), h, w, ps, part=1, nparts=3)
+    ctx.sync()
+    for f in range(n):
+        assert int((out[f].cpu().numpy() != one.cpu().numpy().reshape(-1)).sum()) == 0
+    ps.free()
+    ctx.close()
+
+
 # ---------------------------------------------------------------- one process, several devices ---
 @pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 1000, 1000)])
 def test_multi_device_context_on_one_gpu(R, scene, h, w):

@@ -24,7 +24,13 @@ for s in $SCENES; do for gd in $GDS; do
     d=$OUT/${s}_gd${gd}_p${i}
     timeout 300 rocprofv3 --pmc ${PASSES[$i]} --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s $s -n 1000 -m 1000 -r 3 -v 3 -o grid_div=$gd -o deep_class=$([ "$gd" = "0" ] && echo 3 || echo 0) > $d.log 2>&1
   done
-done; done
+done
+# batch launches (rt_render_batch, what bench.py times): 20 frames per launch, batch-only mode of rtbench
+for i in 0 1 3 4; do
+  d=$OUT/${s}_batch20_p${i}
+  timeout 300 rocprofv3 --pmc ${PASSES[$i]} --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s $s -n 1000 -m 1000 -r 0 -B 20 > $d.log 2>&1
+done
+done
 cd $OLDPWD
 python - "$OUT" <<'PY'
 import csv, glob, os, sys, collections

@@ -21,7 +21,7 @@ cp $OUT/pmc.json $OUT/issue_peak.json profiles/        # on the GPU box only: th
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 {
 export GPU_MAX_HW_QUEUES=20
-for s in rgbbox irreg; do for v in 1 2 3; do echo "== $s 1000x1000 variant $v"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 -v $v $([ $v = 3 ] && echo "-L 24 -o grid_div=4 -o deep_class=0") 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic|Overlapped"; done; done
+for s in rgbbox irreg; do for v in 1 2 3; do echo "== $s 1000x1000 variant $v"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 -v $v $([ $v = 3 ] && echo "-L 24 -B 20 -o grid_div=4 -o deep_class=0") 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic|Overlapped|Batch"; done; done
 for s in rgbbox irreg; do echo "== $s 1000x1000 variant 3, library defaults, one frame at a time"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 2>&1 | grep -E "BVH|Rendering|HIP-event|Throughput"; done
 echo "== irreg 4000x4000 variant 3"; timeout 120 ./build/rtbench -s irreg -n 4000 -m 4000 -r 5 -v 3 2>&1 | grep -E "HIP-event|Throughput|Algorithmic"
 echo "== big 2000x2000 variant 3"; timeout 300 ./build/rtbench -s big -n 2000 -m 2000 -r 3 -v 3 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic"

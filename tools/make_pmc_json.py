@@ -31,7 +31,13 @@ def main():
     doc = {"_comment": __doc__.split("\n\n")[2].replace("\n", " "),
            "source_sha256": bench.kernel_source_hash(), "sources": bench.KERNEL_SOURCES, "launches": {}}
     for run, c in sorted(runs.items()):
-        scene, gd = run.rsplit("_gd", 1)
+        if "_batch" in run:
+            # a batch launch of N frames: per-FRAME figures (the launch's counters / N)
+            scene, nb = run.rsplit("_batch", 1)
+            c = {k: (v / int(nb) if not k.startswith("SQ_WAVES") else v) for k, v in c.items()}
+            gd = None
+        else:
+            scene, gd = run.rsplit("_gd", 1)
         e = {k: int(c[k]) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVES", "SQ_LDS_IDX_ACTIVE",
                                      "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32",
                                      "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_ACTIVE_INST_VALU",
@@ -48,7 +54,10 @@ def main():
         ns = [v for k, v in c.items() if k.startswith("kernel_ns_p")]
         if ns:
             e["kernel_ms_one_at_a_time"] = round(sum(ns) / len(ns) * 1e-6, 4)
-        doc["launches"].setdefault(f"{scene} 1000x1000", {})[f"grid_div={gd}"] = e
+        if gd is None:
+            e["frames_per_launch"] = int(nb)
+            e["note"] = "per frame: counters of one rt_render_batch launch / frames per launch"
+        doc["launches"].setdefault(f"{scene} 1000x1000", {})["batch" if gd is None else f"grid_div={gd}"] = e
     # HBM traffic barely depends on the launch size: reuse the default launch's where it was not measured
     for scene, by in doc["launches"].items():
         base = by.get("grid_div=0", {})

@@ -48,11 +48,11 @@ static void write_ppm(const char *path, const int32_t *px, int h, int w) {
 }
 
 int main(int argc, char **argv) {
-  int h = 200, w = 200, runs = 10, depth = 50, variant = 0, parts = 1, lanes = 1;
+  int h = 200, w = 200, runs = 10, depth = 50, variant = 0, parts = 1, lanes = 1, batch = 0;
   const char *scene_name = "rgbbox", *ppm = NULL;
   const char *opts[32];
   int nopts = 0, c;
-  while ((c = getopt(argc, argv, "s:n:m:r:d:v:o:f:g:L:")) != -1) {
+  while ((c = getopt(argc, argv, "s:n:m:r:d:v:o:f:g:L:B:")) != -1) {
     switch (c) {
     case 's': scene_name = optarg; break;
     case 'n': h = atoi(optarg); break;
@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
     case 'f': ppm = optarg; break;
     case 'g': parts = atoi(optarg); break;
     case 'L': lanes = atoi(optarg); break;
+    case 'B': batch = atoi(optarg); break;
     default:
       fprintf(stderr, "usage: %s [-s scene] [-n height] [-m width] [-r runs] [-d max_depth] [-v variant] [-o k=v] [-f out.ppm] [-g parts]\n", argv[0]);
       return 2;
@@ -106,6 +107,14 @@ int main(int argc, char **argv) {
 
   rt_prepared *ps = NULL;
   double t0 = now_s();
+  uint64_t st[3];
+  int32_t *img = NULL;
+  float *ms = NULL;
+  if (runs == 0 && batch > 1) {
+    /* batch-only mode (what the PMC passes profile): no single-frame launches of the pooled kernel */
+    CHECK(ctx, rt_prepare_scene(ctx, &ps, h, w, scene));
+    CHECK(ctx, rt_render_stats(ctx, ps, h, w, depth, st));
+  } else {
   for (int i = 0; i < runs; i++) {
     if (ps) rt_prepared_free(ctx, ps);
     CHECK(ctx, rt_prepare_scene(ctx, &ps, h, w, scene));
@@ -113,7 +122,6 @@ int main(int argc, char **argv) {
   }
   printf("Scene BVH construction in %fs.\n", (now_s() - t0) / runs);
 
-  int32_t *img = NULL;
   CHECK(ctx, rt_device_alloc(ctx, (void **)&img, (int64_t)sizeof(int32_t) * h * w));
   /* warm-up launch (module load, clocks), then the timed loop */
   CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, 0, 1, img));
@@ -126,13 +134,12 @@ int main(int argc, char **argv) {
   double t_render = (now_s() - t0) / runs;
   printf("Rendering in %fs.\n", t_render);
 
-  float *ms = (float *)malloc(sizeof(float) * (size_t)runs);
+  ms = (float *)malloc(sizeof(float) * (size_t)runs);
   CHECK(ctx, rt_render_timed(ctx, ps, h, w, depth, 8, 0, 1, img, 2, runs, ms));
   double sum = 0, mn = 1e30;
   for (int i = 0; i < runs; i++) { sum += ms[i]; if (ms[i] < mn) mn = ms[i]; }
   double t_kernel = sum / runs * 1e-3;
 
-  uint64_t st[3];
   CHECK(ctx, rt_render_stats(ctx, ps, h, w, depth, st));
   double bytes_alg = 32.0 * (double)st[1] + 16.0 * (double)st[2] + 4.0 * (double)w * h;
   printf("Frame work: %llu rays, %llu box tests, %llu sphere tests, %.0f algorithmic bytes (%.1f B/ray)\n",
@@ -143,6 +150,24 @@ int main(int argc, char **argv) {
          (double)st[0] / t_kernel * 1e-6);
   printf("Algorithmic bandwidth: %.1f GB/s = %.3f of the 8000 GB/s HBM3E roofline\n", bytes_alg / t_kernel * 1e-9,
          bytes_alg / t_kernel * 1e-9 / 8000.0);
+
+  }
+  if (batch > 1 && parts == 1) {
+    int32_t *bimg = NULL;
+    CHECK(ctx, rt_device_alloc(ctx, (void **)&bimg, (int64_t)sizeof(int32_t) * h * w * batch));
+    for (int k = 0; k < 2; k++) CHECK(ctx, rt_render_batch(ctx, ps, h, w, depth, 8, 0, 1, batch, NULL, (int64_t)h * w, bimg));
+    CHECK(ctx, rt_context_sync(ctx));
+    double best = 1e30;
+    for (int rep = 0; rep < 5; rep++) {
+      double tb = now_s();
+      CHECK(ctx, rt_render_batch(ctx, ps, h, w, depth, 8, 0, 1, batch, NULL, (int64_t)h * w, bimg));
+      CHECK(ctx, rt_context_sync(ctx));
+      const double t = (now_s() - tb) / batch;
+      if (t < best) best = t;
+    }
+    printf("Batch: %d frames in one launch: %.4f ms per frame, %.1f Mray/s\n", batch, best * 1e3, (double)st[0] / best * 1e-6);
+    rt_device_free(ctx, bimg);
+  }
 
   if (lanes > 1) {
     /* throughput: `lanes` independent frames in flight (GPU_MAX_HW_QUEUES must allow that many queues) */
@@ -186,7 +211,7 @@ int main(int argc, char **argv) {
     }
   }
 
-  if (ppm) {
+  if (ppm && img) {
     int32_t *host = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
     CHECK(ctx, rt_render_part(ctx, ps, h, w, depth, 8, 0, 1, img));
     CHECK(ctx, rt_copy_to_host(ctx, host, img, (int64_t)sizeof(int32_t) * h * w));
@@ -195,7 +220,7 @@ int main(int argc, char **argv) {
     free(host);
   }
   free(ms);
-  rt_device_free(ctx, img);
+  if (img) rt_device_free(ctx, img);
   rt_prepared_free(ctx, ps);
   rt_scene_free(ctx, scene);
   rt_context_destroy(ctx);
