@@ -411,7 +411,7 @@ def main():
     # untimed warm-up steps, then exactly K timed steps.
     for k in range(2 * S):
         step(k)
-    for k in range(S if (batch and args.warmup > 0) else args.warmup):   # (batch: one more pass of all K >= W steps)
+    for k in range(2 * S if (batch and args.warmup > 0) else args.warmup):   # (batch: two more passes of all K >= W steps)
         step(k)
     torch.cuda.synchronize()
     poison(lanes)
