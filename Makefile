@@ -45,7 +45,12 @@ build/wavesim: tools/wavesim.cpp $(CSRC)/lane_core.h $(CSRC)/rt_host.hpp $(OBJ)/
 	@mkdir -p build
 	$(CXX) $(HOSTFLAGS) -fopenmp -I$(CSRC) -o $@ tools/wavesim.cpp $(OBJ)/host_build.o
 
-tools: build/rtbench
+# microbenchmark behind the bench line's measured peaks (tools/gpu_issue_peak.sh runs it)
+build/issue_peak: tools/issue_peak.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-inline-asm -o $@ $<
+
+tools: build/rtbench build/issue_peak
 
 oracle:
 	$(MAKE) -s -C oracle
