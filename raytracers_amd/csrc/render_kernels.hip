@@ -2,14 +2,18 @@
 // path: render_image / trace_ray / ray_colour / objs_hit / bvh_fold
 // (futhark/ray.fut:126-169, :76-86; futhark/bvh.fut:61-84).
 //
-// Two kernel families, bit-identical output:
+// Three kernel families, bit-identical output:
 //   pixel_kernel       one thread per pixel, 8x8 pixel tile per wave, BVH read from
 //                      HBM/L2 (no LDS staging of the scene)          -> BASELINE configs[1]
 //   persistent_kernel  persistent waves pulling 8x8 tiles from a global ticket counter,
 //                      finished lanes refilled in place (ballot + mbcnt prefix), per-wave
 //                      phase voting {box, sphere, shade}, breadth-first BVH prefix and
-//                      sphere table staged in LDS, traversal stack + deferred-leaf list
-//                      in LDS                                        -> BASELINE configs[2]
+//                      sphere table staged in LDS, per-lane traversal stack + deferred-leaf
+//                      list in LDS
+//   pooled_kernel      (the default) persistent waves whose 64 lanes share LDS work lists of
+//                      (ray slot, node) items: any lane tests any ray's node; one launch renders
+//                      one frame, one device's row tiles of it, or a batch of frames
+//                                                                    -> BASELINE configs[2..4]
 //
 // No MFMA: there is no dense contraction on this path.  Build: -ffp-contract=off and
 // the default correctly rounded fp32 divide/sqrt (parity is bit-exact).
