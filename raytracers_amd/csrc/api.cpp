@@ -299,7 +299,6 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
-  p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -490,12 +489,6 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->lds_sph_first = v != 0;
   } else if (k == "grid_div") {
     ctx->grid_div = std::max(0, std::min(64, v));
-  } else if (k == "low_box") {
-    ctx->low_box = std::max(0, std::min(64, v));
-  } else if (k == "thr_shade_low") {
-    ctx->thr_shade_low = std::max(1, std::min(64, v));
-  } else if (k == "low_leaf") {
-    ctx->low_leaf = std::max(1, std::min(64, v));
   } else if (k == "prio_depth") {
     ctx->prio_depth = std::max(0, v);
   } else if (k == "gpu_build") {
@@ -865,7 +858,6 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
-  p.low_box = ctx->low_box; p.thr_shade_low = ctx->thr_shade_low; p.low_leaf = ctx->low_leaf;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {

@@ -401,11 +401,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       tr_maxbox = nbox > tr_maxbox ? nbox : tr_maxbox;
       tr_maxleaf = nleaf > tr_maxleaf ? nleaf : tr_maxleaf;
     }
-    bool drain = false;    // the leaf list must be emptied before folds can be finished
-    // a short box stack means idle lanes in the coming BOX operations: be more eager to start
-    // new folds then (thr_shade_low applies while nbox < low_box)
-    const int thr = nbox < p.low_box ? p.thr_shade_low : p.thr_shade;
+    // Which operation?  The two common cases first, on two scalar compares: a full leaf batch is drained, else a
+    // full box batch is expanded (the bound on the leaf list needs that order).  Only a wave with less than a
+    // batch in both lists looks at finished folds and vacant slots.
+    bool leaf_op = nleaf >= 64;
     if (nbox < 64 && nleaf < 64) {
+     bool drain = false;    // the leaf list must be emptied before folds can be finished
+     const int thr = p.thr_shade;
      // Not a full wave of work in either list: look at completed folds / vacant slots -- unless even
      // ALL live slots being finished could not reach the threshold (a wave nursing a few deep bounce
      // chains: the look costs an LDS round trip per operation on the frame's critical path).
@@ -571,8 +573,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         }
       }
      }
+     leaf_op = drain | (nbox == 0);
     }
-    if (drain || nleaf >= 64 || nbox == 0 || (nbox < p.low_box && nleaf >= p.low_leaf)) {
+    if (leaf_op) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const int top = nleaf - 1 - lane;

@@ -47,7 +47,6 @@ struct KParams {
   // pooled family
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
-  int low_box, thr_shade_low, low_leaf;   // policy while the box stack is short (see pooled_kernel)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
   int deep_class;        // tickets below order[nchunks + deep_class] are "deep" tiles (0: feature off)
