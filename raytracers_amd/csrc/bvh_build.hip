@@ -384,8 +384,8 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
       q[2 * k + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
     }
   }
-  q[0].w = __int_as_float(ref[0]);
-  q[1].w = __int_as_float(ref[1]);
+  q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted: a pooled work item is (reference << 8) | (slot * 4)
+  q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
   nodes64[4 * (size_t)t + 0] = q[0];
   nodes64[4 * (size_t)t + 1] = q[1];
   nodes64[4 * (size_t)t + 2] = q[2];
@@ -720,8 +720,8 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
       q[2 * k] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(l.x, l.y, l.z, 0.f);
       q[2 * k + 1] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(h.x, h.y, h.z, 0.f);
     }
-    q[0].w = __int_as_float(ref[0]);
-    q[1].w = __int_as_float(ref[1]);
+    q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted (see trav_node)
+    q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
     a.o.nodes64[4 * (size_t)t + 0] = q[0];
     a.o.nodes64[4 * (size_t)t + 1] = q[1];
     a.o.nodes64[4 * (size_t)t + 2] = q[2];

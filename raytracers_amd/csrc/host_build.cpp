@@ -305,8 +305,10 @@ TravLayout make_trav_layout(const Lbvh &b) {
         q[8 * k + 4 + a] = ch.hi[a];
       }
     }
-    std::memcpy(&q[3], &nd.left, 4);
-    std::memcpy(&q[7], &nd.right, 4);
+    // child references pre-shifted: a pooled work item is (reference << 8) | (slot * 4)
+    const int32_t l8 = static_cast<int32_t>(static_cast<uint32_t>(nd.left) << 8), r8 = static_cast<int32_t>(static_cast<uint32_t>(nd.right) << 8);
+    std::memcpy(&q[3], &l8, 4);
+    std::memcpy(&q[7], &r8, 4);
   }
   for (int a = 0; a < 3; ++a) {
     t.root_lo[a] = t.nodes[0].lo[a];

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "lane_core.h"
 #include "rt_device.hpp"
@@ -132,6 +133,19 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 __device__ __forceinline__ int lane_rank(unsigned long long m) {   // # set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ int lane_rank_from(unsigned long long m, int base) {   // base + lane_rank(m): mbcnt's own addend
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
+}
+
+// ds_add_u32 executed by exactly the lanes of a 64-bit mask held in SGPRs (no VALU compare, no branch): the
+// exec mask is narrowed around the one instruction and restored.
+__device__ __forceinline__ void lds_add_masked(unsigned long long m, int lds_byte_addr, int v) {
+  unsigned long long saved;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "s"(m), "v"(lds_byte_addr), "v"(v)
+               : "memory");
 }
 
 template <int THREADS, bool STATS>
@@ -612,56 +626,63 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
-      if (STATS) { tr_ops[0]++; tr_items[0] += nbox < 64 ? nbox : 64; }
-      const int top = nbox - 1 - lane;
-      const unsigned item = wbox[top < 0 ? 0 : top];
-      nbox = uni(nbox > 64 ? nbox - 64 : 0);
-      const int sl4 = (int)(item & 0xfcu);
-      const int ni = (int)(item >> 8);
-      const float4 ra = wray[sl4 >> 2], ri = wray[64 + (sl4 >> 2)];
-      Ray q;
-      q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
-      q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
-      float4 q0, q1, q2, q3;
-      if (ALL_LDS) {
-        q0 = smem[ni]; q1 = smem[plane + ni]; q2 = smem[2 * plane + ni]; q3 = smem[3 * plane + ni];
-      } else {
-        const int li = ni < plane ? ni : 0;
-        q0 = smem[li]; q1 = smem[plane + li]; q2 = smem[2 * plane + li]; q3 = smem[3 * plane + li];
-        if (ni >= plane) {
-          q0 = buf_load16(rs_nodes, ni * 64);
-          q1 = buf_load16(rs_nodes, ni * 64 + 16);
-          q2 = buf_load16(rs_nodes, ni * 64 + 32);
-          q3 = buf_load16(rs_nodes, ni * 64 + 48);
+      // (two instantiations: a FULL batch -- every lane has an item: no clamp, no activity mask -- and the general one)
+      auto box = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if (STATS) { tr_ops[0]++; tr_items[0] += FULL ? 64 : nbox; }
+        const int top = nbox - 1 - lane;
+        const unsigned item = wbox[FULL ? top : (top < 0 ? 0 : top)];
+        const unsigned long long m_act = FULL ? ~0ull : bal(top >= 0);
+        nbox = uni(FULL ? nbox - 64 : 0);
+        const int sl4 = (int)(item & 0xfcu);
+        const int ni16 = (int)((item >> 4) & 0xfffffff0u);   // node index * 16: its byte offset within a plane
+        const float4 *const rayp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wray) + 4 * sl4);
+        const float4 ra = rayp[0], ri = rayp[64];
+        Ray q;
+        q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
+        q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
+        float4 q0, q1, q2, q3;
+        {
+          const int lo16 = ALL_LDS ? ni16 : (ni16 < 16 * plane ? ni16 : 0);
+          const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
+          q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
+          if (!ALL_LDS && ni16 >= 16 * plane) {
+            q0 = buf_load16(rs_nodes, ni16 * 4);
+            q1 = buf_load16(rs_nodes, ni16 * 4 + 16);
+            q2 = buf_load16(rs_nodes, ni16 * 4 + 32);
+            q3 = buf_load16(rs_nodes, ni16 * 4 + 48);
+          }
         }
-      }
-      asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w));   // 16-byte reads throughout
-      const int cl = f2i(q0.w), cr = f2i(q1.w);
-      // lane masks straight from the compares; the rest is 64-bit scalar logic
-      const unsigned long long m_act = bal(top >= 0);
-      const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
-      const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
-      const unsigned long long m_ln = bal(cl < 0), m_rn = bal(cr < 0);
-      // an inner child continues iff its box passes; a leaf child is tested because this node passed
-      const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
-      const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
-      if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
-      // append: left children first, then right children (two independent prefix ranks per list);
-      // ONE store per child: to the box stack, to the leaf list, or to the dump dword
-      const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-      const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
-      const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
-      const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
-      const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * (c_inl + lane_rank(m_inr))),
-                               b_leaf + 4 * (c_lfl + lane_rank(m_lfr)));
-      lds_store(a_l, ((unsigned)cl << 8) | (unsigned)sl4);
-      lds_store(a_r, ((unsigned)cr << 8) | (unsigned)sl4);
-      nbox = uni(nbox + c_inl + __popcll(m_inr));
-      nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
-      // outstanding inner-node items of the slot: one consumed, k in {0, 1, 2} appended.  Only items
-      // with k != 1 touch the counter (same-address LDS atomics serialise).
-      const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
-      if (sel_mask(m_two | m_none, 0, 1) != 0) atomicAdd(&wcnt[sl4 >> 2], sel_mask(m_two, -1, 1));
+        asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w));   // 16-byte reads throughout
+        const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);   // child references, stored pre-shifted by 8 (sign = leaf)
+        // lane masks straight from the compares; the rest is 64-bit scalar logic
+        const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
+        const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+        const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
+        // an inner child continues iff its box passes; a leaf child is tested because this node passed
+        const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
+        const unsigned long long m_lfl = m_act & m_ln, m_lfr = m_act & m_rn;
+        if (STATS) n_box += __popcll(m_act & ~m_ln & (1ull << lane)) + __popcll(m_act & ~m_rn & (1ull << lane));
+        // append: left children first, then right children (two independent prefix ranks per list; the right
+        // children's ranks start at the left children's count: mbcnt's addend).  ONE store per child: to the box
+        // stack, to the leaf list, or to the dump dword
+        const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
+        const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
+        const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+        const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+        const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * lane_rank_from(m_inr, c_inl)),
+                                 b_leaf + 4 * lane_rank_from(m_lfr, c_lfl));
+        lds_store(a_l, (unsigned)cl8 | (unsigned)sl4);
+        lds_store(a_r, (unsigned)cr8 | (unsigned)sl4);
+        nbox = uni(nbox + c_inl + __popcll(m_inr));
+        nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
+        // outstanding inner-node items of the slot: one consumed, k in {0, 1, 2} appended.  Only items with k != 1
+        // touch the counter (same-address LDS atomics serialise): the ds_add runs under exactly their lane mask.
+        const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
+        lds_add_masked(m_two | m_none, (int)(size_t)wcnt + sl4, sel_mask(m_two, -1, 1));
+      };
+      if (nbox >= 64) box(std::true_type{});
+      else box(std::false_type{});
     }
   }
   if (STATS) {

@@ -16,7 +16,7 @@ constexpr int pooled_wave_dw(int ray_planes, int capb, int capl) { return kPoole
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)
   const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
-  const float4 *nodes64; // [4*(n-1)]  pooled family: {L.lo,left} {L.hi,right} {R.lo,0} {R.hi,0} (children's boxes)
+  const float4 *nodes64; // [4*(n-1)]  pooled family: {L.lo,left<<8} {L.hi,right<<8} {R.lo,0} {R.hi,0} (children's boxes)
   const float4 *sph;     // [n] {pos.xyz, radius}
   const float4 *col;     // [n] {colour.rgb, 1/radius}
   float root_lo[3], root_hi[3];   // the root's own box

@@ -75,9 +75,10 @@ struct TravLayout {
   std::vector<float> sph;            // [n][4] pos.xyz, radius
   std::vector<float> col;            // [n][4] colour.rgb, 1/radius (hit normal's scale, ray.fut:44)
   // 64-byte records for the pooled kernel: a work item is an inner node whose own box already
-  // passed, so the record carries what its CHILDREN need: {L.lo.xyz, left} {L.hi.xyz, right}
+  // passed, so the record carries what its CHILDREN need: {L.lo.xyz, left << 8} {L.hi.xyz, right << 8}
   // {R.lo.xyz, 0} {R.hi.xyz, 0}, where L/R are the child's box when the child is an inner node
-  // (unused for a leaf child: the reference keeps no leaf boxes, bvh.fut:84).
+  // (unused for a leaf child: the reference keeps no leaf boxes, bvh.fut:84).  The references are stored
+  // pre-shifted: a work item of the pooled kernel is (reference << 8) | (slot * 4).
   std::vector<float> nodes64;        // [n-1][16] breadth-first
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};   // box of the root (tested when a ray starts)
   std::vector<int32_t> bfs_of_canon; // canonical inner index -> traversal index
