@@ -12,8 +12,8 @@ the framebuffers of a step are gathered to rank 0 over RCCL inside the timed reg
 gather per step: a rank's rows of both frames travel in one send buffer).
 
 Steps are independent frames, so the K timed steps are handed to the library's throughput entry,
-rt_render_batch: ONE launch per scene renders that scene's frame of all K steps (on N > 1 GPUs: two
-chunks of K/2 steps, so that the first chunk's gather overlaps the second chunk's rendering) -- the
+rt_render_batch: ONE launch per scene renders that scene's frame of all K steps (the scenes' launches on
+separate streams; on N > 1 GPUs each has its own framebuffer gather) -- the
 persistent waves run straight across frame boundaries and the launch's fill and drain are paid once.
 All K steps complete inside the barrier/synchronize bracket.  (--protocol lanes is the round-1
 protocol: one launch per frame, up to --frames-in-flight steps overlapped on separate HIP streams.)
@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
     ap.add_argument("--protocol", choices=["batch", "lanes"], default="batch",
                     help="batch: one rt_render_batch launch per scene and chunk; lanes: one launch per frame, frames overlapped on streams")
-    ap.add_argument("--chunks", type=int, default=0, help="batch protocol: launches per scene (0: 1 on one GPU, 2 on several)")
+    ap.add_argument("--chunks", type=int, default=0, help="batch protocol: launches per scene (0 = 1)")
     ap.add_argument("--frames-in-flight", type=int, default=10, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
@@ -292,12 +292,18 @@ def main():
     opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
     batch = args.protocol == "batch" and args.variant in (0, 3)
     if batch:
-        # K steps in C launches per scene (C = 1 on one GPU; 2 on several, so that a chunk's gather overlaps the next chunk's
-        # rendering); library-default knobs: a batch launch uses every persistent workgroup and no dedicated deep-tile waves
-        C = max(1, min(args.chunks or (1 if world == 1 else 2), args.steps))
-        chunk_sizes = [args.steps // C + (1 if i < args.steps % C else 0) for i in range(C)]
-        S = C
+        # K steps in C launches per scene (default 1: every launch ends with the frame's longest bounce chain, ~0.5 ms that
+        # a rank with an eighth of the rows cannot afford twice), the scenes' launches on separate streams (they overlap
+        # where one's tail leaves CUs idle; each has its own gather).  One-GPU stand-in for a rank's share of K = 20 steps
+        # (tools/rank_share_probe.py, us per step, slowest part): W = 1 / 2 / 4 / 8 = 377 / 197 / 114 / 95 with full-size
+        # launches, 76 at W = 8 with half-size ones (two scenes side by side instead of one after the other).
+        C = max(1, min(args.chunks or 1, args.steps))
+        chunk_sizes = [args.steps // C + (1 if i < args.steps % C else 0) for i in range(C) for _ in frames]
+        lane_frames = [[fr] for _ in range(C) for fr in frames]
+        S = len(chunk_sizes)
         opts_pipe = dict(opts)
+        if world >= 8:
+            opts_pipe.setdefault("grid_div", 2)
     else:
         # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).  Ten lanes at
         # a quarter-size launch each were the best of {6, 10, 20} x grid_div {2, 4, 8} at the driver's K = 20
@@ -305,6 +311,7 @@ def main():
         # lanes only lengthen the queue -- and the drain at the end of the bracket.
         S = max(1, min(args.frames_in_flight, args.steps))
         chunk_sizes = [1] * S
+        lane_frames = [frames] * S
         # With many frames in flight a launch need not fill the machine by itself: a quarter of the
         # persistent workgroups per launch gives longer-lived, better-filled waves; the longer tail is
         # hidden by the other frames.  One frame at a time keeps the library default.
@@ -320,16 +327,18 @@ def main():
     class Lane:
         """the renderers of one launch in flight + the step (render all, one gather, assemble)"""
         def __init__(self, o, fr=frames, nbatch=1):
+            self.fr = fr
             self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in fr]
             self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch)
 
     lanes = []
-    for st, nb in zip(streams, chunk_sizes):
+    for st, nb, fr in zip(streams, chunk_sizes, lane_frames):
         with torch.cuda.stream(st):
-            lanes.append(Lane(opts_pipe, nbatch=nb))
+            lanes.append(Lane(opts_pipe, fr, nbatch=nb))
     serial_lane = Lane(opts) if ((S > 1 or batch) and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
-    renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, lanes[0].prs)]
+    renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, serial_lane.prs if serial_lane else
+                                                                 [ln.prs[0] for ln in lanes[:len(frames)]] if batch else lanes[0].prs)]
 
     # work per frame: instrumented launch (rank 0 is enough), checked against the oracle table
     work = {}
@@ -365,13 +374,13 @@ def main():
 
     cks = Checksummer(device)
 
-    def verify(which, fr, what):
-        """rank 0: every image of every lane (a batch lane holds nbatch of them per scene) against the oracle's checksums"""
+    def verify(which, what):
+        """rank 0: every image of every lane (a batch lane holds nbatch of them) against the oracle's checksums"""
         bad = []
         n = 0
         if rank == 0:
             for li, ln in enumerate(which):
-                for (scene, h, w), imgs in zip(fr, ln.step.images):
+                for (scene, h, w), imgs in zip(ln.fr, ln.step.images):
                     want = FRAME_CHECKSUM.get((scene, h, w))
                     if want is None:
                         continue
@@ -389,7 +398,8 @@ def main():
         batch protocol: every lane's launches once (together they cover exactly K steps); nlanes == 0: the serial lane"""
         every = max(1, args.event_every)
         nlaunch = S if (batch and nlanes != 0) else nsteps
-        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
+        lane_of = (lambda k: serial_lane) if nlanes == 0 else (lambda k: lanes[k % nlanes])
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lane_of(k).fr]
               if k % every == 0 else None for k in range(nlaunch)]
         fence()
         t0 = time.perf_counter()
@@ -402,8 +412,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         # per-launch durations on this rank: events recorded on the stream each kernel is launched on
-        kms = [float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(nlaunch) if ev[k] is not None]))
-               for i in range(len(frames))]
+        per = {fr: [] for fr in frames}
+        for k in range(nlaunch):
+            if ev[k] is not None:
+                for fr, (a, b) in zip(lane_of(k).fr, ev[k]):
+                    per[fr].append(a.elapsed_time(b))
+        kms = [float(np.mean(per[fr])) for fr in frames]
         return dt, kms
 
     # Lane set-up: every lane renders its frames twice, which fills the per-view caches (u/v tables;
@@ -416,7 +430,7 @@ def main():
     torch.cuda.synchronize()
     poison(lanes)
     elapsed, kern_ms = timed(args.steps, S)
-    n_verified = verify(lanes, frames, "timed region,")
+    n_verified = verify(lanes, "timed region,")
     serial = None
     if serial_lane is not None:
         for k in range(3):
@@ -425,7 +439,7 @@ def main():
         poison([serial_lane])
         nser = max(10, args.steps // 2)
         serial = timed(nser, 0)
-        n_verified += verify([serial_lane], frames, "serial region,")
+        n_verified += verify([serial_lane], "serial region,")
 
     # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
     scale_extra = None
@@ -451,7 +465,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmin = t.clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        n_verified += verify([big_lane], fr4, "irreg 4000x4000,")
+        n_verified += verify([big_lane], "irreg 4000x4000,")
+        # ... and the same frames as ONE batch launch per rank (one frame at a time cannot end before its longest bounce chain)
+        del big_lane
+        bb = Lane(opts, fr4, nbatch=n4)
+        for _ in range(2):
+            bb.step.render()
+        torch.cuda.synchronize()
+        poison([bb])
+        fence()
+        t0 = time.perf_counter()
+        bb.step.render()
+        fence()
+        tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        n_verified += verify([bb], "irreg 4000x4000 batch,")
+        del bb
         if rank == 0:
             r4 = FRAME_WORK[("irreg", 4000, 4000)][0]
             ms = float(tmax[0].item()) / n4 * 1e3
@@ -459,8 +488,10 @@ def main():
                            "ms_per_frame": ms, "Mray_s": r4 / ms / 1e3,
                            "render_us_per_rank": {"slowest": float(tmax[1].item()) * 1e3, "fastest": float(tmin[1].item()) * 1e3},
                            "gather_and_assemble_us_rank0": float(np.mean([a.elapsed_time(b) for a, b in evg])) * 1e3,
+                           "batch": {"frames_per_launch": n4, "ms_per_frame": float(tb[0].item()) / n4 * 1e3,
+                                     "Mray_s": r4 * n4 / float(tb[0].item()) / 1e6,
+                                     "note": "the same frames in one rt_render_batch launch per rank + one gather"},
                            "frames": n4, "verified": True}
-        del big_lane
 
     if rank == 0:
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)
@@ -481,8 +512,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "verified": True, "verified_images": n_verified,
-            "value_protocol": (f"batched throughput: the {args.steps} steps' frames of each scene in {S} rt_render_batch launch(es) of "
-                               f"{'/'.join(str(c) for c in chunk_sizes)} frames, all inside the timed bracket" if batch else
+            "value_protocol": (f"batched throughput: the {args.steps} steps' frames of each scene in {S // len(frames)} rt_render_batch "
+                               f"launch(es) of {'/'.join(str(c) for c in chunk_sizes[::len(frames)])} frames (the scenes on separate "
+                               "streams), all inside the timed bracket" if batch else
                                f"overlapped throughput: {S} independent frames in flight on {S} HIP streams, all {args.steps} steps inside "
                                "the timed bracket") + "; the reference's protocol (one render + sync at a time) is serial_value",
             "config": {"workload": " + ".join(f"{s} {w}x{h}" for s, h, w in frames) + ", max_depth 50, one frame of each per step",

@@ -785,6 +785,7 @@ def test_bench_line_two_ranks_sharing_the_gpu():
     r = d["irreg_4000"]
     assert r["verified"] is True and r["ms_per_frame"] > 0 and r["Mray_s"] > 0
     assert r["render_us_per_rank"]["slowest"] >= r["render_us_per_rank"]["fastest"] > 0 and r["gather_and_assemble_us_rank0"] > 0
+    assert r["batch"]["ms_per_frame"] > 0 and r["batch"]["frames_per_launch"] == r["frames"]
 
 
 def test_bench_refuses_wrong_pixels(tmp_path):

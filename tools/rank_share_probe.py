@@ -1,44 +1,54 @@
-"""How fast can ONE rank turn over its share of a step at world size W?  One-GPU stand-in for
-the strong-scaling run: renders part p of W for every frame of the workload on S lanes (HIP
-streams), no exchange.  With part = all, every part is measured in turn and the slowest one
-(what a real W-GPU step would wait for) is reported.
+"""How fast can ONE rank turn over its share of the bench's K steps at world size W?  One-GPU stand-in for the
+strong-scaling run (batch protocol of bench.py): for every part p of W, the K steps' frames of each scene in C batch
+launches (rt_render_batch) of this part's rows -- no exchange -- and, for irreg 4000x4000, one frame at a time.  The
+slowest part is what a real W-GPU run would wait for.
 
-usage: rank_share_probe.py <workload> W S grid_div [part|all] [steps]
-       workload: 1000 (rgbbox + irreg 1000x1000, the bench step) | irreg4000
-       (GPU_MAX_HW_QUEUES from the environment, default 20)"""
-import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+usage: rank_share_probe.py [K=20] [worlds=1,2,4,8]"""
+import sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from raytracers_amd.dist import HipPartRenderer, max_part_rows
 
-wl, W, S, gd = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-part = sys.argv[5] if len(sys.argv) > 5 else str(W - 1)
-n = int(sys.argv[6]) if len(sys.argv) > 6 else 400
-frames = {"1000": [("rgbbox", 1000, 1000), ("irreg", 1000, 1000)], "irreg4000": [("irreg", 4000, 4000)]}[wl]
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
+CH = int(sys.argv[3]) if len(sys.argv) > 3 else 0       # chunks per scene (0: bench.py's default)
+GD = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # grid_div of the batch launches (0: library default)
+TWO = len(sys.argv) > 5 and sys.argv[5] == "2s"         # the two scenes' launches on two streams
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
-streams = [torch.cuda.Stream(dev) for _ in range(S)]
-lanes = []
-for st in streams:
+frames = [("rgbbox", 1000, 1000), ("irreg", 1000, 1000)]
+streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if TWO else [torch.cuda.current_stream(dev)] * 2
+prs = []
+for (s_, h_, w_), st in zip(frames, streams):
     with torch.cuda.stream(st):
-        prs = [HipPartRenderer(s, h, w, dev, options={"grid_div": gd}) for s, h, w in frames]
-        outs = [torch.zeros((max_part_rows(h, W), w), dtype=torch.int32, device=dev) for _, h, w in frames]
-        lanes.append((prs, outs))
-torch.cuda.synchronize()
-worst = 0.0
-for p in (range(W) if part == "all" else [int(part)]):
-    def step(k):
-        li = k % S
-        with torch.cuda.stream(streams[li]):
-            prs, outs = lanes[li]
-            for pr, o in zip(prs, outs):
-                pr(p, W, o)
-    for k in range(2 * S): step(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(n): step(k)
-    torch.cuda.synchronize()
-    us = 1e6 * (time.perf_counter() - t0) / n
-    worst = max(worst, us)
-    print(f"Q={os.environ['GPU_MAX_HW_QUEUES']} {wl} W={W} S={S} grid_div={gd} part {p}: {us:.1f} us/step", flush=True)
-print(f"RESULT {wl} W={W} S={S} grid_div={gd}: slowest part {worst:.1f} us/step", flush=True)
+        prs.append(HipPartRenderer(s_, h_, w_, dev, options={"grid_div": GD} if GD else None))
+big = HipPartRenderer("irreg", 4000, 4000, dev)
+for W in worlds:
+    C = CH or (1 if W == 1 else 2)
+    sizes = [K // C + (1 if i < K % C else 0) for i in range(C)]
+    res, res4 = [], []
+    for p in range(W):
+        outs = [[torch.zeros((nb * max_part_rows(h, W), w), dtype=torch.int32, device=dev) for _, h, w in frames] for nb in sizes]
+        def run():
+            for nb, o in zip(sizes, outs):
+                for pr, (_, h, w), t, st in zip(prs, frames, o, streams):
+                    with torch.cuda.stream(st):
+                        pr.batch(p, W, nb, t, max_part_rows(h, W) * w)
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): run()
+        torch.cuda.synchronize()
+        res.append(1e6 * (time.perf_counter() - t0) / 5 / K)
+        o4 = torch.zeros((max_part_rows(4000, W), 4000), dtype=torch.int32, device=dev)
+        for _ in range(3): big(p, W, o4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            big(p, W, o4)
+            torch.cuda.synchronize()
+        res4.append(1e6 * (time.perf_counter() - t0) / 5)
+    print(f"W={W}: K={K} steps in {C} batch launch(es) per scene: {max(res):.1f} us/step slowest part, {min(res):.1f} fastest "
+          f"(render-share scaling {res_1 / max(res):.2f}x); " if W > 1 else f"W=1: {max(res):.1f} us/step; ", end="")
+    if W == 1: res_1, res4_1 = max(res), max(res4)
+    print(f"irreg 4000x4000 one frame: {max(res4):.0f} us slowest part, {min(res4):.0f} fastest"
+          + (f" ({res4_1 / max(res4):.2f}x)" if W > 1 else ""), flush=True)
