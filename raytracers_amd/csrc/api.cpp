@@ -299,6 +299,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
+  p.box2 = ctx->box2;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -495,6 +496,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->gpu_build = v != 0;
   } else if (k == "adaptive_order") {
     ctx->adaptive_order = v;
+  } else if (k == "box2") {
+    ctx->box2 = v != 0;
   } else if (k == "ray_planes") {
     if (v != 0 && v != 2 && v != 3) return fail(ctx, "ray_planes must be 0 (auto), 2 or 3");
     ctx->ray_planes = v;
@@ -858,6 +861,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
+  p.box2 = ctx->box2;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {

@@ -681,7 +681,86 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
         lds_add_masked(m_two | m_none, (int)(size_t)wcnt + sl4, sel_mask(m_two, -1, 1));
       };
+      // ---- BOX2: at most 32 items, TWO lanes and TWO tree levels each.  A wave with a nearly empty stack is on some
+      // frame's critical path (a long bounce chain advances one operation per tree level): lane 2k handles the LEFT child
+      // of item k, lane 2k+1 the RIGHT one -- tests the child's box (from the item's record) and, if it passes, reads the
+      // CHILD's record and tests the grandchildren's boxes, appending those.  Exactly the tests of two consecutive BOX
+      // operations (a grandchild is tested iff its parent's box passed) for one operation's fixed latencies plus one LDS
+      // round trip.
+      auto box2 = [&]() {
+        if (STATS) { tr_ops[0]++; tr_items[0] += nbox; }
+        const int role = lane & 1;
+        const int top = nbox - 1 - (lane >> 1);
+        const unsigned item = wbox[top < 0 ? 0 : top];
+        const bool act = top >= 0;
+        nbox = uni(0);
+        const int sl4 = (int)(item & 0xfcu);
+        const int ni16 = (int)((item >> 4) & 0xfffffff0u);
+        const float4 *const rayp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wray) + 4 * sl4);
+        const float4 ra = rayp[0], ri = rayp[64];
+        Ray q;
+        q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
+        q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
+        // this lane's child: its box is quarters (2 role, 2 role + 1) of the item's record, its reference the .w of quarter `role`
+        float4 lo, hi;
+        int ref;
+        {
+          const bool res = ALL_LDS || ni16 < 16 * plane;
+          const int lo16 = res ? ni16 : 0;
+          const char *const np = reinterpret_cast<const char *>(smem) + lo16;
+          lo = *reinterpret_cast<const float4 *>(np + 32 * role * plane);
+          hi = *reinterpret_cast<const float4 *>(np + (32 * role + 16) * plane);
+          ref = f2i(reinterpret_cast<const float4 *>(np + 16 * role * plane)->w);
+          if (!ALL_LDS && !res) {
+            lo = buf_load16(rs_nodes, ni16 * 4 + 32 * role);
+            hi = buf_load16(rs_nodes, ni16 * 4 + 32 * role + 16);
+            ref = f2i(buf_load16(rs_nodes, ni16 * 4 + 16 * role).w);
+          }
+        }
+        const bool child_leaf = act & (ref < 0);
+        const bool pass = act & (ref >= 0) && box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+        if (STATS) n_box += (act & (ref >= 0)) ? 1 : 0;
+        // second level: the child's own record (a virtual item `ref | sl4`)
+        const int ci16 = pass ? (int)(((unsigned)ref >> 4) & 0xfffffff0u) : 0;
+        float4 q0, q1, q2, q3;
+        {
+          const int lo16 = ALL_LDS ? ci16 : (ci16 < 16 * plane ? ci16 : 0);
+          const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
+          q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
+          if (!ALL_LDS && ci16 >= 16 * plane) {
+            q0 = buf_load16(rs_nodes, ci16 * 4);
+            q1 = buf_load16(rs_nodes, ci16 * 4 + 16);
+            q2 = buf_load16(rs_nodes, ci16 * 4 + 32);
+            q3 = buf_load16(rs_nodes, ci16 * 4 + 48);
+          }
+        }
+        asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w), "v"(lo.w), "v"(hi.w));
+        const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);
+        const unsigned long long m_pass = bal(pass), m_cleaf = bal(child_leaf);
+        const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
+        const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+        const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
+        const unsigned long long m_inl = m_pass & ~m_ln & m_hl, m_inr = m_pass & ~m_rn & m_hr;
+        // leaf appends: the child itself (lanes whose child is a leaf), or its leaf children -- never both for one lane
+        const unsigned long long m_lfl = (m_pass & m_ln) | m_cleaf, m_lfr = m_pass & m_rn;
+        if (STATS) n_box += __popcll(m_pass & ~m_ln & (1ull << lane)) + __popcll(m_pass & ~m_rn & (1ull << lane));
+        const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
+        const int dump = (int)(size_t)(wdump);
+        const int b_box = (int)(size_t)(wbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+        const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+        const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * lane_rank_from(m_inr, c_inl)),
+                                 b_leaf + 4 * lane_rank_from(m_lfr, c_lfl));
+        lds_store(a_l, (unsigned)sel_mask(m_cleaf, cl8, ref) | (unsigned)sl4);
+        lds_store(a_r, (unsigned)cr8 | (unsigned)sl4);
+        nbox = uni(c_inl + __popcll(m_inr));
+        nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
+        // the slot's counter of outstanding inner-node items: this lane's appended inner grandchildren, minus the item
+        // itself (counted once, by the pair's even lane)
+        const int d = sel_mask(m_inl, 0, 1) + sel_mask(m_inr, 0, 1) - sel_mask(bal(act & (role == 0)), 0, 1);
+        lds_add_masked(bal(d != 0), (int)(size_t)wcnt + sl4, d);
+      };
       if (nbox >= 64) box(std::true_type{});
+      else if (nbox <= 32 && p.box2) box2();
       else box(std::false_type{});
     }
   }

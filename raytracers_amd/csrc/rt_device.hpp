@@ -49,6 +49,7 @@ struct KParams {
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
+  int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int deep_class;        // tickets below order[nchunks + deep_class] are "deep" tiles (0: feature off)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)

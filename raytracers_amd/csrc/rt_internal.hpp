@@ -32,6 +32,7 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
+  int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int ray_planes = 0;       // pooled family: planes of the LDS ray table (0 = chosen with the workgroup shape, 2, 3)
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)

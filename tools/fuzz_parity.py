@@ -57,7 +57,7 @@ while time.time() < t_end:
     knobs = dict(grid_div=int(rng.choice([0, 1, 2, 4, 8, 16])), thr_shade=int(rng.choice([1, 8, 24, 48, 64])),
                  deep_class=int(rng.integers(0, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
                  lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])),
-                 wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])))
+                 wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):
