@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="kernel knob name=value (repeatable)")
     ap.add_argument("--protocol", choices=["batch", "lanes"], default="batch",
                     help="batch: one rt_render_batch launch per scene and chunk; lanes: one launch per frame, frames overlapped on streams")
+    ap.add_argument("--launch-order", choices=["reversed", "listed"], default="reversed",
+                    help="batch protocol: which scene's launch goes first (reversed: irreg before rgbbox)")
     ap.add_argument("--chunks", type=int, default=0, help="batch protocol: launches per scene (0 = 1)")
     ap.add_argument("--frames-in-flight", type=int, default=10, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
@@ -299,7 +301,10 @@ def main():
         # launches, 76 at W = 8 with half-size ones (two scenes side by side instead of one after the other).
         C = max(1, min(args.chunks or 1, args.steps))
         chunk_sizes = [args.steps // C + (1 if i < args.steps % C else 0) for i in range(C) for _ in frames]
-        lane_frames = [[fr] for _ in range(C) for fr in frames]
+        # launch order: the LAST scene first.  Persistent workgroups of two launches do not share a CU (each fills its LDS), so
+        # the launches run one after the other with an overlap at the seam; irreg's launch ends with ~0.5 ms of lone bounce
+        # chains, which rgbbox's launch fills when it comes second (measured: 0.395 -> see DESIGN.md 6)
+        lane_frames = [[fr] for _ in range(C) for fr in (reversed(frames) if args.launch_order == "reversed" else frames)]
         S = len(chunk_sizes)
         opts_pipe = dict(opts)
         if world >= 8:
@@ -338,7 +343,7 @@ def main():
     serial_lane = Lane(opts) if ((S > 1 or batch) and not args.no_serial_extra) else None   # on the default stream
     torch.cuda.synchronize()
     renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, serial_lane.prs if serial_lane else
-                                                                 [ln.prs[0] for ln in lanes[:len(frames)]] if batch else lanes[0].prs)]
+                                                                 [next(ln.prs[0] for ln in lanes if ln.fr[0] == fr) for fr in frames] if batch else lanes[0].prs)]
 
     # work per frame: instrumented launch (rank 0 is enough), checked against the oracle table
     work = {}

@@ -334,6 +334,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.cost = rerecord ? to->cost : nullptr;
       p.order = to->valid ? to->order : nullptr;
       p.deep_class = ctx->deep_class;
+      p.deep_split = ctx->deep_split;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
@@ -503,6 +504,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->ray_planes = v;
   } else if (k == "deep_class") {
     ctx->deep_class = std::min(8, std::max(0, v));
+  } else if (k == "deep_split") {
+    ctx->deep_split = std::min(3, std::max(0, v));
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -822,7 +825,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   Plan pl{};
   const int saved = ctx->variant;
   ctx->variant = RT_VARIANT_POOLED;
-  int rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8), 8);   // the instrumented instantiation is the 512-thread one
+  // the instrumented kernel exists for workgroups of 16 and of 8 waves: the production plan's shape if it is one of those
+  int rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8));
+  if (rc || pl.variant != RT_VARIANT_POOLED || (pl.waves != 16 && pl.waves != 8)) rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8), 8);
   ctx->variant = saved;
   if (rc) return rc;
   const int nw = pl.grid * pl.waves;
@@ -871,6 +876,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           ctx->adaptive_order && o.ntiles == p.nchunks) {
         p.order = o.order;
         p.deep_class = ctx->deep_class;
+        p.deep_split = ctx->deep_split;
       }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(nw);

@@ -398,6 +398,15 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // end before its longest chain does, and a chain advances ~3x faster in a wave that is not
   // busy with 63 other rays' work.
   bool hold = false;
+  // ... and a deep tile is handed out in 2^deep_split pieces (tickets), to as many waves: its 64 rays in one wave are 30-40
+  // operations per bounce while most of them are alive, a quarter of them in each of four waves about ten.  The first
+  // n_split tiles of the order are the deep ones: tickets [0, n_split << deep_split) are their pieces.
+  // Only the deepest of them, though: the pieces may occupy a 32nd of the launch's waves (rgbbox 1000x1000 has 158 tiles
+  // with chains of >= 32 bounces -- as quarters they would park 15 % of the waves on 16 rays each).
+  const int n_deep = (p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split > 0) ? p.order[p.nchunks + p.deep_class] : 0;
+  const int n_split = min(n_deep, (int)(gridDim.x * (THREADS / 64)) >> (5 + p.deep_split));
+  const unsigned extra_tickets = (unsigned)n_split * ((1u << p.deep_split) - 1u);
+  bool q_enter = false;    // a ticket was drawn: (re)derive the tile's position
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   int tr_maxdepth = 0, tr_maxbox = 0, tr_maxleaf = 0;
@@ -492,17 +501,26 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
               t = __builtin_amdgcn_readfirstlane(t);
               const unsigned total = (unsigned)p.nchunks * (unsigned)p.nframes;
-              const unsigned first = t << p.tpt_log2;
-              if (first >= total) {
-                exhausted = true;
-                if (STATS) tr_exh = wall_clock64();
-                break;
+              if (t < ((unsigned)n_split << p.deep_split)) {
+                // a piece of a deep tile: 64 >> deep_split consecutive pixels (whole rows) of tile number t >> deep_split
+                const unsigned piece = 64u >> p.deep_split;
+                q_next = (t >> p.deep_split) * 64u + (t & ((1u << p.deep_split) - 1u)) * piece;
+                q_end = q_next + piece;
+              } else {
+                const unsigned first = (t - extra_tickets) << p.tpt_log2;   // (extra_tickets != 0 only where tpt_log2 == 0)
+                if (first >= total) {
+                  exhausted = true;
+                  if (STATS) tr_exh = wall_clock64();
+                  break;
+                }
+                const unsigned last = first + (1u << p.tpt_log2);
+                q_next = first * 64u;
+                q_end = (last < total ? last : total) * 64u;
               }
-              const unsigned last = first + (1u << p.tpt_log2);
-              q_next = first * 64u;
-              q_end = (last < total ? last : total) * 64u;
+              q_enter = true;
             }
-            if ((q_next & 63u) == 0u) {
+            if (q_enter || (q_next & 63u) == 0u) {
+              q_enter = false;
               // entering a tile: where it is.  A batch launch hands out the tiles of frame 0, then of frame 1, ...:
               // frame f's pixels go to out + f * frame_stride and (when the batch carries cameras) through cams[f]
               unsigned t = q_next >> 6;
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               q_col0 = (q_tile - ty * p.tiles_x) * 8;
               q_row0 = ty * 8;
             }
-            const unsigned avail = 64u - (q_next & 63u);   // rest of the current tile
+            const unsigned rest = 64u - (q_next & 63u), avail = rest < q_end - q_next ? rest : q_end - q_next;   // rest of the current tile / piece
             const unsigned rank = (unsigned)lane_rank(m);
             const unsigned cnt = (unsigned)__popcll(m);
             if (want & (rank < avail)) {
@@ -764,6 +782,15 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       else box(std::false_type{});
     }
   }
+  // The host counts on tiles + waves ticket draws per launch (queue_base): the last wave to leave takes the deep tiles'
+  // extra tickets back off the counter.
+  if (extra_tickets != 0u && lane == 0) {
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    if (atomicAdd(&p.queue[1], 1u) == nwaves - 1u) {
+      p.queue[1] = 0u;
+      atomicSub(p.queue, extra_tickets);
+    }
+  }
   if (STATS) {
     atomicAdd(&p.stats[0], n_rays);
     atomicAdd(&p.stats[1], n_box);
@@ -790,61 +817,56 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
 // chain (a 50-bounce pixel is ~50 x (tree height + 3) dependent wave operations), so chains
 // must START early.  Every frame records per tile the longest chain it saw (p.cost); this
 // kernel turns the record into the ticket -> tile table of the NEXT frame of the same
-// prepared scene: a stable counting sort by cost class (floor(log2), descending), and clears
-// the record.  It only permutes the order in which independent pixels are traced.
+// prepared scene: a stable counting sort by chain length, descending (64 bins: the exact length
+// up to 62 bounces), and clears the record.  Behind the table it stores the first ticket of each
+// of the kOrderClasses coarse classes (floor(log2) of the length) -- the deep-tile threshold and
+// the class-major ticket order of a batch are expressed in those.  It only permutes the order in
+// which independent pixels are traced.
 // ---------------------------------------------------------------------------------
-constexpr int kOrderThreads = 1024;
+constexpr int kOrderThreads = 128;
+constexpr int kOrderBins = 64;
+
+__device__ __forceinline__ int order_bin(int v) { return kOrderBins - 1 - min(kOrderBins - 1, max(v, 0)); }   // 0 = longest chains
 
 __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles) {
-  __shared__ int hist[kOrderClasses][kOrderThreads];   // [class][thread], 32 KB
-  __shared__ int class_base[kOrderClasses + 1];
+  __shared__ int hist[kOrderBins][kOrderThreads];   // [bin][thread], 32 KB: counts, then exclusive positions
+  __shared__ int bin_base[kOrderBins + 1];
   const int t = threadIdx.x;
   const int per = (ntiles + kOrderThreads - 1) / kOrderThreads;
   const int begin = t * per, end = min(ntiles, begin + per);
-  int local[kOrderClasses];
-#pragma unroll
-  for (int c = 0; c < kOrderClasses; ++c) local[c] = 0;
-  for (int i = begin; i < end; ++i) {
-    const int v = cost[i];
-    const int cls = kOrderClasses - 1 - min(kOrderClasses - 1, v > 0 ? 31 - __clz(v) : 0);   // 0 = most expensive
-#pragma unroll
-    for (int c = 0; c < kOrderClasses; ++c) local[c] += (c == cls) ? 1 : 0;
-  }
-#pragma unroll
-  for (int c = 0; c < kOrderClasses; ++c) hist[c][t] = local[c];
+  for (int b = 0; b < kOrderBins; ++b) hist[b][t] = 0;
+  for (int i = begin; i < end; ++i) hist[order_bin(cost[i])][t] += 1;   // a thread touches its own column only
   __syncthreads();
-  // exclusive scan of each class row across threads (one wave-free serial pass per class by 8 threads
-  // would be slow: 1024 entries; use a simple Hillis-Steele in place)
-  for (int off = 1; off < kOrderThreads; off <<= 1) {
-    int add[kOrderClasses];
-#pragma unroll
-    for (int c = 0; c < kOrderClasses; ++c) add[c] = t >= off ? hist[c][t - off] : 0;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kOrderClasses; ++c) hist[c][t] += add[c];
-    __syncthreads();
+  // exclusive scan of each bin's row across the threads (thread order = tile order: the sort is stable);
+  // one thread per bin walks its row, the row total lands in bin_base
+  if (t < kOrderBins) {
+    int acc = 0;
+    for (int k = 0; k < kOrderThreads; ++k) {
+      const int c = hist[t][k];
+      hist[t][k] = acc;
+      acc += c;
+    }
+    bin_base[t] = acc;
   }
+  __syncthreads();
   if (t == 0) {
     int acc = 0;
-    for (int c = 0; c < kOrderClasses; ++c) {
-      class_base[c] = acc;
-      acc += hist[c][kOrderThreads - 1];
+    for (int b = 0; b < kOrderBins; ++b) {
+      const int c = bin_base[b];
+      bin_base[b] = acc;
+      acc += c;
     }
-    class_base[kOrderClasses] = acc;
-    // first ticket of each cost class (class c = chains of 2^(7-c) .. 2^(8-c) - 1 bounces): the
-    // render kernel treats the tickets below order[ntiles + deep_class] as deep tiles
-    for (int c = 0; c <= kOrderClasses; ++c) order[ntiles + c] = class_base[c];
+    bin_base[kOrderBins] = acc;
+    // first ticket of each coarse class (class c = chains of 2^(7-c) .. 2^(8-c) - 1 bounces): the render kernel
+    // treats the tickets below order[ntiles + deep_class] as deep tiles, a batch hands tickets out class-major
+    for (int c = 0; c < kOrderClasses; ++c) order[ntiles + c] = bin_base[order_bin((1 << (kOrderClasses - c)) - 1)];
+    order[ntiles + kOrderClasses] = acc;
   }
   __syncthreads();
-  int pos[kOrderClasses];
-#pragma unroll
-  for (int c = 0; c < kOrderClasses; ++c) pos[c] = class_base[c] + hist[c][t] - local[c];   // inclusive -> exclusive
   for (int i = begin; i < end; ++i) {
-    const int v = cost[i];
-    const int cls = kOrderClasses - 1 - min(kOrderClasses - 1, v > 0 ? 31 - __clz(v) : 0);
-#pragma unroll
-    for (int c = 0; c < kOrderClasses; ++c)
-      if (c == cls) order[pos[c]++] = i;
+    const int b = order_bin(cost[i]);
+    order[bin_base[b] + hist[b][t]] = i;
+    hist[b][t] += 1;
     cost[i] = 0;
   }
 }
@@ -957,7 +979,7 @@ static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
-  if (stats) return launch_pooled_t<512, false, true>(p, grid, stream);
+  if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   switch (waves_per_wg) {
   case 4: return all_lds ? launch_pooled_t<256, true, false>(p, grid, stream) : launch_pooled_t<256, false, false>(p, grid, stream);
   case 8: return all_lds ? launch_pooled_t<512, true, false>(p, grid, stream) : launch_pooled_t<512, false, false>(p, grid, stream);

@@ -37,7 +37,7 @@ struct KParams {
   unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
   unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
   // persistent family
-  unsigned *queue;       // monotonic ticket counter (never reset; see Context::queue_base)
+  unsigned *queue;       // [0] monotonic ticket counter (never reset; see Context::queue_base)  [1] waves that have left (deep-tile pieces)
   unsigned queue_base;   // counter value at which this launch's ticket 0 sits
   int nchunks;           // 8x8 tiles in this part
   int lds_nodes;         // breadth-first node prefix staged in LDS
@@ -51,6 +51,7 @@ struct KParams {
   const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int deep_class;        // tickets below order[nchunks + deep_class] are "deep" tiles (0: feature off)
+  int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row

@@ -39,6 +39,7 @@ struct rt_context {
   int grid_div = 0;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups; 0 = by frame size
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
+  int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
   // ticket counter of the persistent family: monotonic across launches, never reset.
   // A launch with C chunks and W waves performs exactly C + W atomic increments (every
   // wave stops at its first out-of-range ticket), so the next launch's base is known.

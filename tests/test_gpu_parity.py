@@ -358,18 +358,21 @@ def test_repeated_launches_share_the_ticket_counter(R, ctx, variant):
         assert (R.render(100, 36, ps_b) == wb).all()
 
 
-@pytest.mark.parametrize("adaptive,deep_class", [(0, 3), (1, 3), (2, 3), (1, 0), (1, 5), (2, 8)])
+@pytest.mark.parametrize("adaptive,deep_class,deep_split", [(0, 3, 2), (1, 3, 2), (2, 3, 2), (1, 0, 2), (1, 5, 1), (2, 8, 2), (1, 8, 3),
+                                                            (1, 5, 0), (2, 6, 3)])
 @pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 200, 200)])
-def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive, deep_class):
-    """The pooled family reorders tiles by the previous frame's bounce-chain record (and gives the
-    deepest tiles a wave that does not refill while they are in flight: deep_class).  Frames
-    1..5 of the same prepared scene must each write every pixel (buffer poisoned before every
-    frame) and stay bit-exact; a second size interleaved in between must not disturb it."""
+def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive, deep_class, deep_split):
+    """The pooled family reorders tiles by the previous frame's bounce-chain record, gives the deepest tiles a wave that
+    does not refill while they are in flight (deep_class) and hands the very deepest out in 2^deep_split pieces, each to
+    a wave of its own (extra tickets, taken back off the ticket counter by the last wave).  Frames 1..5 of the same prepared
+    scene must each write every pixel (buffer poisoned before every frame) and stay bit-exact; a second size interleaved
+    in between must not disturb it (it shares the context's ticket counter)."""
     import torch
     c = R.Context()
     c.set_variant(3)
     c.set_option("adaptive_order", adaptive)
     c.set_option("deep_class", deep_class)   # 8: every recorded tile is "deep" (its wave does not refill meanwhile)
+    c.set_option("deep_split", deep_split)
     ps = R.prepare_scene(h, w, c.scene(scene))
     ps2 = R.prepare_scene(64, 72, c.scene(scene))
     want, _ = _oracle(scene).render(h, w)

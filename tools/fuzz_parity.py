@@ -57,7 +57,8 @@ while time.time() < t_end:
     knobs = dict(grid_div=int(rng.choice([0, 1, 2, 4, 8, 16])), thr_shade=int(rng.choice([1, 8, 24, 48, 64])),
                  deep_class=int(rng.integers(0, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
                  lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])),
-                 wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])))
+                 wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])),
+                 deep_split=int(rng.integers(0, 4)))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):
@@ -73,6 +74,8 @@ while time.time() < t_end:
             px = R.render(h, w, ps, max_depth=md)
             px2 = R.render(h, w, ps, max_depth=md)      # second frame: adaptive tile order / deep tiles
             ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
+            if variant == 3:                            # third frame: the ticket counter after a frame with deep-tile pieces
+                ok &= int((R.render(h, w, ps, max_depth=md) != ref).sum()) == 0
     # the row-tile partition: every part rendered on its own, assembled in one launch
     ctx.set_option("gpu_build", 1)
     ctx.set_variant(0)
