@@ -50,7 +50,12 @@ build/issue_peak: tools/issue_peak.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-inline-asm -o $@ $<
 
-tools: build/rtbench build/issue_peak
+# the pooled kernel's tile-queue protocol (rt_device.hpp) played on the CPU; in the CPU test suite
+build/queue_check: tools/queue_check.cpp $(CSRC)/rt_device.hpp $(CSRC)/lane_core.h
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Wall -I$(CSRC) -o $@ $<
+
+tools: build/rtbench build/issue_peak build/queue_check
 
 oracle:
 	$(MAKE) -s -C oracle

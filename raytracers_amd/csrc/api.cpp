@@ -288,12 +288,15 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     return 0;
   }
   p.nframes = nframes;
-  p.tpt_log2 = nframes > 1 ? 2 : 0;
   p.frame_stride = static_cast<int>(frame_stride);
   p.cams = reinterpret_cast<const rtk::Cam *>(cams_dev);
   p.queue = ctx->queue_dev;
-  p.queue_base = ctx->queue_base;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
+  // tiles per ticket: one ticket counter saturates at ~88 draws per microsecond, which batches and large frames reach
+  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : ((nframes > 1 || p.nchunks >= 32768) ? 2 : 0);
+  // one ticket counter and one strip of tile columns per XCD (workgroup b runs on XCD b % 8)
+  p.nshards = (ctx->xcd_queues && nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
@@ -308,7 +311,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (ctx->adaptive_order && !p.cams) {   // (a batch with its own cameras has no single view to order tiles by)
       for (auto &o : ps->orders)
         if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
-            o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks)
+            o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks &&
+            o.nshards == p.nshards)
           to = &o;
       if (!to) {
         if (ps->orders.size() >= 8) {   // bounded: forget the oldest view
@@ -321,8 +325,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         o.h = h; o.w = w; o.rows_per_tile = rows_per_tile; o.part = part; o.nparts = nparts; o.max_depth = max_depth;
         std::memcpy(o.cam, &p.cam, sizeof o.cam);
         o.ntiles = p.nchunks;
+        o.nshards = p.nshards;
         RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
-        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * (static_cast<size_t>(o.ntiles) + 16)));
+        RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(o.ntiles))));
         RT_HIP(ctx, hipMemsetAsync(o.cost, 0, sizeof(int) * static_cast<size_t>(o.ntiles), ctx->stream));
         ps->orders.push_back(o);
         to = &ps->orders.back();
@@ -339,14 +344,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
       // next frames' ticket -> tile table from this frame's record (also clears the record)
-      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, ctx->stream));
+      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->stream));
       to->valid = true;
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
-  // every wave stops at its first out-of-range ticket: tickets drawn = ceil(tiles / tiles per ticket) + waves
-  const unsigned tiles_total = static_cast<unsigned>(p.nchunks) * static_cast<unsigned>(p.nframes);
-  ctx->queue_base += ((tiles_total + (1u << p.tpt_log2) - 1) >> p.tpt_log2) + static_cast<unsigned>(pl.grid) * pl.waves;
   return 0;
 }
 using rti::enqueue_render;
@@ -388,8 +390,8 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(6);
     ctx->own_stream = true;
   }
-  if (hipMalloc(reinterpret_cast<void **>(&ctx->queue_dev), 256) != hipSuccess) return bail(7);
-  if (hipMemset(ctx->queue_dev, 0, 256) != hipSuccess) return bail(7);
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->queue_dev), sizeof(unsigned) * rtk::kQueueDwords) != hipSuccess) return bail(7);
+  if (hipMemset(ctx->queue_dev, 0, sizeof(unsigned) * rtk::kQueueDwords) != hipSuccess) return bail(7);
   if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return bail(7);
   if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return bail(7);
   if (hipMalloc(reinterpret_cast<void **>(&ctx->arena), kArenaGranules * kGranule) != hipSuccess) return bail(7);
@@ -400,6 +402,10 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   rtk::warm_render_kernels();
   rtk::warm_build_kernels();
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
+  // (test aids: the whole suite under the other queue layouts)
+  if (const char *v = std::getenv("RT_XCD_QUEUES")) ctx->xcd_queues = std::atoi(v) != 0;
+  if (const char *v = std::getenv("RT_TPT_LOG2")) ctx->tpt_log2 = std::max(-1, std::min(4, std::atoi(v)));
+  if (const char *v = std::getenv("RT_STATIC_FIRST")) ctx->static_first = std::atoi(v) != 0;
   *out = ctx.release();
   return 0;
 }
@@ -448,12 +454,11 @@ extern "C" int rt_context_sync(rt_context *ctx) {
     }
   }
   if (q == hipSuccess) return 0;
-  // A launch that died leaves the device-side ticket counter out of step with queue_base (the host
-  // assumes every launch performs nchunks + waves increments): every later frame would draw
-  // out-of-range tickets and silently render nothing.  Re-zero both.
+  // A launch that died leaves the ticket counters non-zero (its last wave never zeroed them): every later
+  // frame would draw out-of-range tickets and silently render nothing.  Re-zero them.
   (void)hipGetLastError();
-  if (hipMemset(ctx->queue_dev, 0, 256) == hipSuccess) ctx->queue_base = 0;
-  return hip_fail(ctx, q, "stream synchronisation (the ticket counter was reset)");
+  (void)hipMemset(ctx->queue_dev, 0, sizeof(unsigned) * rtk::kQueueDwords);
+  return hip_fail(ctx, q, "stream synchronisation (the ticket counters were reset)");
 }
 
 extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
@@ -506,6 +511,13 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->deep_class = std::min(8, std::max(0, v));
   } else if (k == "deep_split") {
     ctx->deep_split = std::min(3, std::max(0, v));
+  } else if (k == "xcd_queues") {
+    ctx->xcd_queues = v != 0;
+  } else if (k == "tpt_log2") {
+    if (v < -1 || v > 4) return fail(ctx, "tpt_log2 must be -1 (auto) or 0..4");
+    ctx->tpt_log2 = v;
+  } else if (k == "static_first") {
+    ctx->static_first = v != 0;
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -859,8 +871,11 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.nframes = 1;
   p.stats = ctx->stats_dev;
   p.trace = trace;
-  p.queue = ctx->queue_dev; p.queue_base = ctx->queue_base;
+  p.queue = ctx->queue_dev;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
+  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (p.nchunks >= 32768 ? 2 : 0);
+  p.nshards = (ctx->xcd_queues && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
@@ -873,13 +888,12 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
     // use the adaptive order of the matching view if one exists (read-only here)
     for (auto &o : ps->orders)
       if (o.h == h && o.w == w && o.part == 0 && o.nparts == 1 && o.max_depth == max_depth && o.valid &&
-          ctx->adaptive_order && o.ntiles == p.nchunks) {
+          ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == p.nshards) {
         p.order = o.order;
         p.deep_class = ctx->deep_class;
         p.deep_split = ctx->deep_split;
       }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
-    ctx->queue_base += static_cast<unsigned>(p.nchunks) + static_cast<unsigned>(nw);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
   }

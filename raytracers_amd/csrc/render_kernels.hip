@@ -148,6 +148,16 @@ __device__ __forceinline__ void lds_add_masked(unsigned long long m, int lds_byt
                : "memory");
 }
 
+// A wave leaves the tile queue (it has failed once on every counter): the last one to leave zeroes the counters,
+// so every launch starts from ticket 0 with no host-side bookkeeping.  (All other waves' draws precede their own
+// arrival here; the resets are device-scope atomics like the draws.)
+__device__ __forceinline__ void queue_leave(const KParams &p, unsigned nwaves, int lane) {
+  if (lane == 0 && atomicAdd(&p.queue[kQueueExit], 1u) == nwaves - 1u) {
+    for (int s = 0; s < kMaxShards; ++s) atomicExch(&p.queue[kQueueStride * s], 0u);
+    atomicExch(&p.queue[kQueueExit], 0u);
+  }
+}
+
 template <int THREADS, bool STATS>
 __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
   const int SMAX = p.smax, LMAX = p.lmax;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
       while (m != 0ull) {            // wave-uniform loop
         if (q_next == q_end) {
           unsigned t = 0;
-          if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
+          if (lane == 0) t = atomicAdd(p.queue, 1u);
           t = __builtin_amdgcn_readfirstlane(t);
           if (t >= (unsigned)p.nchunks) {
             exhausted = true;
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
       }
     }
   }
+  queue_leave(p, gridDim.x * (THREADS / 64), lane);
   if (STATS) {
     atomicAdd(&p.stats[0], n_rays);
     atomicAdd(&p.stats[1], n_box);
@@ -403,9 +414,23 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // n_split tiles of the order are the deep ones: tickets [0, n_split << deep_split) are their pieces.
   // Only the deepest of them, though: the pieces may occupy a 32nd of the launch's waves (rgbbox 1000x1000 has 158 tiles
   // with chains of >= 32 bounces -- as quarters they would park 15 % of the waves on 16 rays each).
-  const int n_deep = (p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split > 0) ? p.order[p.nchunks + p.deep_class] : 0;
-  const int n_split = min(n_deep, (int)(gridDim.x * (THREADS / 64)) >> (5 + p.deep_split));
-  const unsigned extra_tickets = (unsigned)n_split * ((1u << p.deep_split) - 1u);
+  // (per shard of the queue: a 32nd of the shard's home waves)
+  const bool deep_on = p.nframes == 1 && p.order != nullptr && p.deep_class > 0;
+  // The queue is sharded (rt_device.hpp): this wave's home shard is its workgroup's XCD; its first ticket is its own
+  // number among the home shard's waves (consecutive tickets -- the deepest tiles -- land on different CUs), the
+  // counters hand out the tickets behind those.
+  const unsigned nwaves = gridDim.x * (THREADS / 64);
+  const int ns_log2 = p.nshards > 1 ? 3 : 0;
+  auto queue_const = [&]() {   // (built where it is used: nothing of it stays live across the render loop)
+    QueueConst qc;
+    qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.nchunks / p.tiles_x; qc.nframes = p.nframes;
+    qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.ntiles = p.nchunks;
+    qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
+    qc.home_waves = nwaves >> ns_log2;                       // the same for every shard (the grid is a multiple of nshards)
+    qc.q_static = p.static_first ? qc.home_waves : 0u;
+    return qc;
+  };
+  unsigned q_state = queue_state_init((int)(blockIdx.x & ((1u << ns_log2) - 1u)), p.static_first != 0);
   bool q_enter = false;    // a ticket was drawn: (re)derive the tile's position
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
@@ -495,28 +520,25 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           while (m != 0ull) {            // wave-uniform loop
             if (q_next == q_end) {
               if (hold) break;           // a deep tile is in flight: no further tickets for now
-              // one ticket = 1 << tpt_log2 consecutive tiles (a batch launch draws four at a time: 4096 waves on one
-              // counter otherwise saturate it -- ~90 atomics per microsecond -- before they saturate the chip)
-              unsigned t = 0;
-              if (lane == 0) t = atomicAdd(p.queue, 1u) - p.queue_base;
-              t = __builtin_amdgcn_readfirstlane(t);
-              const unsigned total = (unsigned)p.nchunks * (unsigned)p.nframes;
-              if (t < ((unsigned)n_split << p.deep_split)) {
-                // a piece of a deep tile: 64 >> deep_split consecutive pixels (whole rows) of tile number t >> deep_split
-                const unsigned piece = 64u >> p.deep_split;
-                q_next = (t >> p.deep_split) * 64u + (t & ((1u << p.deep_split) - 1u)) * piece;
-                q_end = q_next + piece;
-              } else {
-                const unsigned first = (t - extra_tickets) << p.tpt_log2;   // (extra_tickets != 0 only where tpt_log2 == 0)
-                if (first >= total) {
-                  exhausted = true;
-                  if (STATS) tr_exh = wall_clock64();
-                  break;
-                }
-                const unsigned last = first + (1u << p.tpt_log2);
-                q_next = first * 64u;
-                q_end = (last < total ? last : total) * 64u;
+              // A ticket: 1 << tpt_log2 consecutive positions of a shard's segment (a batch launch and a large frame draw
+              // four tiles at a time: 4096 waves on one counter otherwise saturate it -- ~90 atomics per microsecond --
+              // before they saturate the chip), except that the first tickets of a shard are pieces of its deepest tiles
+              // (64 >> deep_split consecutive pixels: whole rows).  The wave's very first ticket costs no atomic.
+              TicketSpan sp;
+              const QueueConst qc = queue_const();
+              const unsigned wave_rank = (unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2);
+              const bool got = queue_draw(q_state, qc, wave_rank, [&](int shard) {
+                unsigned v = 0;
+                if (lane == 0) v = atomicAdd(&p.queue[kQueueStride * shard], 1u);
+                return (unsigned)__builtin_amdgcn_readfirstlane(v);
+              }, &sp);
+              if (!got) {
+                exhausted = true;
+                if (STATS) tr_exh = wall_clock64();
+                break;
               }
+              q_next = sp.q_next;
+              q_end = sp.q_end;
               q_enter = true;
             }
             if (q_enter || (q_next & 63u) == 0u) {
@@ -543,8 +565,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 q_frame_off = (int)(f * (unsigned)p.frame_stride);
                 if (p.cams != nullptr) q_cam = p.cams[f];
               }
-              q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
-              if (p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && (int)t < p.order[p.nchunks + p.deep_class]) {
+              const QueueConst qc = queue_const();
+              const Shard q_s = shard_of(queue_shard(q_state), ns_log2, qc.tiles_x, qc.tiles_y);   // the shard the ticket came from
+              q_tile = p.order != nullptr ? p.order[t] : shard_tile(q_s, (int)t - q_s.seg, p.tiles_x);   // uniform (scalar) load
+              if (deep_on && (int)t - q_s.seg < queue_ndeep(qc, queue_shard(q_state))) {
                 hold = true;
                 __builtin_amdgcn_s_setprio(3);
               }
@@ -782,15 +806,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       else box(std::false_type{});
     }
   }
-  // The host counts on tiles + waves ticket draws per launch (queue_base): the last wave to leave takes the deep tiles'
-  // extra tickets back off the counter.
-  if (extra_tickets != 0u && lane == 0) {
-    const unsigned nwaves = gridDim.x * (THREADS / 64);
-    if (atomicAdd(&p.queue[1], 1u) == nwaves - 1u) {
-      p.queue[1] = 0u;
-      atomicSub(p.queue, extra_tickets);
-    }
-  }
+  queue_leave(p, nwaves, lane);
   if (STATS) {
     atomicAdd(&p.stats[0], n_rays);
     atomicAdd(&p.stats[1], n_box);
@@ -828,14 +844,19 @@ constexpr int kOrderBins = 64;
 
 __device__ __forceinline__ int order_bin(int v) { return kOrderBins - 1 - min(kOrderBins - 1, max(v, 0)); }   // 0 = longest chains
 
-__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles) {
+// One workgroup per shard of the tile queue: it sorts its strip's tiles (row-major within the strip) into the
+// strip's segment of the table and writes the shard's class table behind the table.
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles, int tiles_x, int nshards) {
   __shared__ int hist[kOrderBins][kOrderThreads];   // [bin][thread], 32 KB: counts, then exclusive positions
   __shared__ int bin_base[kOrderBins + 1];
   const int t = threadIdx.x;
-  const int per = (ntiles + kOrderThreads - 1) / kOrderThreads;
-  const int begin = t * per, end = min(ntiles, begin + per);
+  const Shard sh = shard_of((int)blockIdx.x, nshards > 1 ? 3 : 0, tiles_x, ntiles / tiles_x);
+  const int n = sh.ntiles;
+  int *const table = order + ntiles + kOrderTableDw * (int)blockIdx.x;
+  const int per = (n + kOrderThreads - 1) / kOrderThreads;
+  const int begin = min(n, t * per), end = min(n, begin + per);
   for (int b = 0; b < kOrderBins; ++b) hist[b][t] = 0;
-  for (int i = begin; i < end; ++i) hist[order_bin(cost[i])][t] += 1;   // a thread touches its own column only
+  for (int i = begin; i < end; ++i) hist[order_bin(cost[shard_tile(sh, i, tiles_x)])][t] += 1;   // a thread touches its own column only
   __syncthreads();
   // exclusive scan of each bin's row across the threads (thread order = tile order: the sort is stable);
   // one thread per bin walks its row, the row total lands in bin_base
@@ -859,21 +880,22 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, in
     bin_base[kOrderBins] = acc;
     // first ticket of each coarse class (class c = chains of 2^(7-c) .. 2^(8-c) - 1 bounces): the render kernel
     // treats the tickets below order[ntiles + deep_class] as deep tiles, a batch hands tickets out class-major
-    for (int c = 0; c < kOrderClasses; ++c) order[ntiles + c] = bin_base[order_bin((1 << (kOrderClasses - c)) - 1)];
-    order[ntiles + kOrderClasses] = acc;
+    for (int c = 0; c < kOrderClasses; ++c) table[c] = bin_base[order_bin((1 << (kOrderClasses - c)) - 1)];
+    table[kOrderClasses] = acc;
   }
   __syncthreads();
   for (int i = begin; i < end; ++i) {
-    const int b = order_bin(cost[i]);
-    order[bin_base[b] + hist[b][t]] = i;
+    const int tile = shard_tile(sh, i, tiles_x);
+    const int b = order_bin(cost[tile]);
+    order[sh.seg + bin_base[b] + hist[b][t]] = tile;
     hist[b][t] += 1;
-    cost[i] = 0;
+    cost[tile] = 0;
   }
 }
 
-hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream) {
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, ntiles);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(nshards), dim3(kOrderThreads), 0, stream, cost, order, ntiles, tiles_x, nshards);
   return hipGetLastError();
 }
 

@@ -13,6 +13,115 @@ constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>
 constexpr int kPooledWaveFixedDw = 128 + 64 + 4;
 constexpr int pooled_wave_dw(int ray_planes, int capb, int capl) { return kPooledWaveFixedDw + 256 * ray_planes + capb + capl; }
 
+// ---- the tile queue of the persistent families --------------------------------------------------
+// Tickets are drawn with returning device-scope atomics; one word saturates at ~88 draws per microsecond
+// (MI355X_MICROARCH.md, "dequeue"), which a 4000x4000 frame's 250 000 tiles reach.  So the queue is SHARDED:
+// nshards in {1, 8} counters, each on its own 128-byte line.  With 8 shards, shard s is the s-th vertical strip
+// of tile columns and the home of the workgroups with blockIdx % 8 == s -- the workgroups one XCD runs -- so an
+// XCD's L2 (4 MiB, not shared with the others) serves one strip's part of the scene; a wave whose home shard has
+// run dry takes tickets from the next shards (every wave fails exactly once on every counter before it leaves).
+// The last wave to leave zeroes the counters for the next launch on the stream.
+constexpr int kQueueStride = 32;                                // dwords between the shards' counters
+constexpr int kMaxShards = 8;
+constexpr int kQueueExit = kQueueStride * kMaxShards;           // dword index of the counter of waves that have left
+constexpr int kQueueDwords = kQueueStride * (kMaxShards + 1);
+// Behind the ticket -> tile table of a view (order[0 .. ntiles)) sits one table per shard: the first position
+// (relative to the shard's segment) of each of the 8 cost classes, then the shard's tile count.
+constexpr int kOrderTableDw = 16;
+constexpr int order_table_ints(int ntiles) { return ntiles + kOrderTableDw * kMaxShards; }
+
+struct Shard {
+  int x0, sw;      // tile columns [x0, x0 + sw)
+  int seg;         // first position of the shard's segment in the order table
+  int ntiles;
+};
+// (the number of shards is 1 << ns_log2: 1 or 8)
+__host__ __device__ inline Shard shard_of(int s, int ns_log2, int tiles_x, int tiles_y) {
+  const int x0 = (s * tiles_x) >> ns_log2, x1 = ((s + 1) * tiles_x) >> ns_log2;
+  return Shard{x0, x1 - x0, x0 * tiles_y, (x1 - x0) * tiles_y};
+}
+// k-th tile of a strip, row-major within the strip -> index in the image's tile grid (one shard: the identity)
+__host__ __device__ inline int shard_tile(const Shard &sh, int k, int tiles_x) {
+  const int r = k / sh.sw;
+  return r * tiles_x + sh.x0 + (k - r * sh.sw);
+}
+// Tickets of a shard with `npos` positions (tiles x frames): its first n_split positions (the deepest tiles of
+// the order) are handed out in 2^ds pieces each, the others 2^tpt positions per ticket.
+__host__ __device__ inline unsigned shard_tickets(unsigned npos, unsigned n_split, int ds, int tpt) {
+  return (n_split << ds) + ((npos - n_split + (1u << tpt) - 1u) >> tpt);
+}
+// ticket t < shard_tickets(...) -> the pixels it covers, as [q_next, q_end) in units of (position * 64 + pixel in tile)
+struct TicketSpan { unsigned q_next, q_end; };
+__host__ __device__ inline TicketSpan ticket_span(unsigned t, unsigned seg, unsigned npos, unsigned n_split, int ds, int tpt) {
+  TicketSpan sp;
+  if (t < (n_split << ds)) {
+    const unsigned piece = 64u >> ds;
+    sp.q_next = (seg + (t >> ds)) * 64u + (t & ((1u << ds) - 1u)) * piece;
+    sp.q_end = sp.q_next + piece;
+  } else {
+    const unsigned k0 = n_split + ((t - (n_split << ds)) << tpt);
+    const unsigned k1 = k0 + (1u << tpt) < npos ? k0 + (1u << tpt) : npos;
+    sp.q_next = (seg + k0) * 64u;
+    sp.q_end = (seg + k1) * 64u;
+  }
+  return sp;
+}
+
+// Drawing a ticket (wave-uniform; shared by the kernel and tools/queue_check.cpp, which plays the protocol on the
+// CPU).  `fetch_add(shard)` returns the shard's counter before its increment.
+struct QueueConst {
+  int ns_log2, tiles_x, tiles_y, nframes;
+  int ds, tpt;               // deep_split, tpt_log2
+  int ntiles;                // all shards' tiles: the class tables sit at order[ntiles + kOrderTableDw * shard]
+  const int *order;          // nullptr: no tables
+  int deep_class;            // 0: no deep tiles
+  unsigned home_waves;       // waves whose home is one shard (total waves >> ns_log2)
+  unsigned q_static;         // tickets [0, q_static) of every shard are the home waves' first tickets: never drawn from the counter
+};
+// A wave's queue state is one word (it lives in an SGPR across the whole render loop):
+// bits 0-2 the shard being drawn from, bit 7 "the first draw is still to come", bits 8-15 the shards seen dry.
+constexpr unsigned kQueueFirst = 0x80u;
+__host__ __device__ inline unsigned queue_state_init(int home_shard, bool static_first) {
+  return (unsigned)home_shard | (static_first ? kQueueFirst : 0u);
+}
+__host__ __device__ inline int queue_shard(unsigned state) { return (int)(state & 7u); }
+// deep tiles at the head of a shard's segment (0: none / feature off)
+__host__ __device__ inline int queue_ndeep(const QueueConst &c, int shard) {
+  return (c.order != nullptr && c.deep_class > 0) ? c.order[c.ntiles + kOrderTableDw * shard + c.deep_class] : 0;
+}
+template <class FetchAdd>
+__host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c, unsigned wave_rank, FetchAdd &&fetch_add, TicketSpan *sp) {
+  const unsigned all = ((1u << (1 << c.ns_log2)) - 1u) << 8;
+  for (;;) {   // until a shard yields a ticket or all have run dry
+    const int sh = queue_shard(state);
+    const Shard s = shard_of(sh, c.ns_log2, c.tiles_x, c.tiles_y);
+    const int ndeep = queue_ndeep(c, sh);
+    const int cap = (int)(c.home_waves >> (5 + c.ds));   // the pieces may occupy a 32nd of the shard's home waves
+    const unsigned n_split = c.ds > 0 ? (unsigned)(ndeep < cap ? ndeep : cap) : 0u;
+    const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
+    const unsigned tickets = shard_tickets(npos, n_split, c.ds, c.tpt);
+    unsigned t = 0;
+    bool got = false;
+    if (state & kQueueFirst) {
+      state &= ~kQueueFirst;
+      t = wave_rank;
+      got = t < tickets;           // (not: the shard has no tickets beyond the static ones either)
+    } else if (tickets > c.q_static) {
+      t = fetch_add(sh) + c.q_static;
+      got = t < tickets;
+    }
+    if (got) {
+      *sp = ticket_span(t, (unsigned)s.seg, npos, n_split, c.ds, c.tpt);
+      return true;
+    }
+    state |= 0x100u << sh;
+    if ((state & all) == all) return false;
+    unsigned nx = (unsigned)sh;
+    do nx = (nx + 1u) & ((1u << c.ns_log2) - 1u); while ((state >> (8 + nx)) & 1u);
+    state = (state & ~7u) | nx;
+  }
+}
+
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)
   const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
@@ -37,8 +146,9 @@ struct KParams {
   unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
   unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
   // persistent family
-  unsigned *queue;       // [0] monotonic ticket counter (never reset; see Context::queue_base)  [1] waves that have left (deep-tile pieces)
-  unsigned queue_base;   // counter value at which this launch's ticket 0 sits
+  unsigned *queue;       // [kQueueDwords] ticket counter of shard s at [kQueueStride * s], waves that have left at [kQueueExit]; all zero between launches
+  int nshards;           // 1, or 8 (pooled family, one frame per launch): one ticket counter and one strip of tile columns per XCD
+  int static_first;      // pooled family: a wave's first ticket is its own number within its home shard (no atomic: no ramp at launch)
   int nchunks;           // 8x8 tiles in this part
   int lds_nodes;         // breadth-first node prefix staged in LDS
   int lds_sph;           // sphere prefix staged in LDS
@@ -48,9 +158,9 @@ struct KParams {
   int capb, capl;        // per-wave box-stack / leaf-list capacities (dwords)
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
-  const int *order;      // [nchunks + 16] ticket -> tile (nullptr: identity), then the first ticket of each cost class
+  const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
-  int deep_class;        // tickets below order[nchunks + deep_class] are "deep" tiles (0: feature off)
+  int deep_class;        // a shard's positions below its class table's entry [deep_class] are "deep" tiles (0: feature off)
   int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)
@@ -82,7 +192,7 @@ size_t gpu_build_pinned_bytes();         // host-pinned block the build kernels 
 hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, char *scratch, char *pinned, hipStream_t stream,
                          int *height_out, float root_lo[3], float root_hi[3]);
 
-hipError_t launch_tile_order(int *cost, int *order, int ntiles, hipStream_t stream);
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

@@ -40,11 +40,12 @@ struct rt_context {
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
   int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
-  // ticket counter of the persistent family: monotonic across launches, never reset.
-  // A launch with C chunks and W waves performs exactly C + W atomic increments (every
-  // wave stops at its first out-of-range ticket), so the next launch's base is known.
+  int xcd_queues = 0;       // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp)
+  int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers (-1: 2 for batches and frames of >= 32768 tiles, else 0)
+  int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
+  // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
+  // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
   unsigned *queue_dev = nullptr;
-  unsigned queue_base = 0;
   unsigned long long *stats_dev = nullptr;
   // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
   struct UvTable {
@@ -88,8 +89,9 @@ struct TileOrder {
   int32_t rows_per_tile, part, nparts, max_depth;
   float cam[12];
   int ntiles = 0;
+  int nshards = 1;        // shards of the tile queue the table is laid out for (segments + class tables)
   int *cost = nullptr;    // [ntiles] record written by the render kernel
-  int *order = nullptr;   // [ntiles] ticket -> tile table for the next frame
+  int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
 };
 

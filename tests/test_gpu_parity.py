@@ -347,7 +347,8 @@ def test_persistent_knobs_do_not_change_pixels(R, opts, variant):
 
 @pytest.mark.parametrize("variant", [2, 3])
 def test_repeated_launches_share_the_ticket_counter(R, ctx, variant):
-    """The persistent families' work queue is a monotonic counter that is never reset."""
+    """The persistent families share the context's ticket counters: the last wave of a launch to leave the queue
+    zeroes them, so launches of different sizes and families follow each other with no host-side bookkeeping."""
     ctx.set_variant(variant)
     ps_a = R.prepare_scene(64, 64, ctx.rgbbox())
     ps_b = R.prepare_scene(100, 36, ctx.irreg())
@@ -364,7 +365,7 @@ def test_repeated_launches_share_the_ticket_counter(R, ctx, variant):
 def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive, deep_class, deep_split):
     """The pooled family reorders tiles by the previous frame's bounce-chain record, gives the deepest tiles a wave that
     does not refill while they are in flight (deep_class) and hands the very deepest out in 2^deep_split pieces, each to
-    a wave of its own (extra tickets, taken back off the ticket counter by the last wave).  Frames 1..5 of the same prepared
+    a wave of its own (extra tickets at the head of the queue).  Frames 1..5 of the same prepared
     scene must each write every pixel (buffer poisoned before every frame) and stay bit-exact; a second size interleaved
     in between must not disturb it (it shares the context's ticket counter)."""
     import torch
@@ -388,6 +389,61 @@ def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive, deep_
         c.sync()
         assert int((out.cpu().numpy() != want).sum()) == 0, frame
         assert int((out2.cpu().numpy() != want2).sum()) == 0, frame
+    c.close()
+
+
+@pytest.mark.parametrize("xcd,tpt,static_first", [(1, -1, 1), (1, 0, 0), (1, 2, 1), (1, 4, 0), (0, 1, 1), (0, 3, 0), (0, -1, 0)])
+@pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 1000, 1000), ("irreg", 40, 24)])
+def test_tile_queue_layouts_render_every_pixel(R, scene, h, w, xcd, tpt, static_first):
+    """The tile queue of the pooled family: one ticket counter and one strip of tile columns per XCD (xcd_queues) with
+    stealing, several tiles per ticket (tpt_log2), the waves' first tickets handed out without an atomic (static_first) --
+    combined with the adaptive order, deep tiles and their pieces.  Frames 0..3 of a view (recording frame, then ordered
+    ones), a part of a three-way row partition and a batch of three frames must each write every pixel (buffers poisoned)
+    and stay bit-exact; the counters must come back to zero after every launch (the next launch relies on it)."""
+    import torch
+    c = R.Context()
+    c.set_variant(3)
+    c.set_option("xcd_queues", xcd)
+    c.set_option("tpt_log2", tpt)
+    c.set_option("static_first", static_first)
+    c.set_option("deep_class", 5)            # chains of >= 8 bounces count as deep: plenty of held waves and pieces
+    ps = R.prepare_scene(h, w, c.scene(scene))
+    want, _ = _oracle(scene).render(h, w)
+    out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+    for frame in range(4):
+        out.fill_(-1)
+        torch.cuda.synchronize()
+        R.render_into(out.data_ptr(), h, w, ps)
+        c.sync()
+        assert int((out.cpu().numpy() != want).sum()) == 0, frame
+    # one part of three (its own view of the tile grid: fewer tile rows, the same strips)
+    rows = R.part_rows(h, 1, 3)
+    if rows:
+        part = torch.full((rows, w), -1, dtype=torch.int32, device="cuda")
+        for frame in range(3):
+            part.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
+            c.sync()
+            from raytracers_amd.dist import tile_rows
+            assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, frame
+    # a batch (one counter whatever xcd_queues says: class-major over the frames), twice: recording launch, ordered launch
+    nb = 3
+    batch = torch.empty((nb, h, w), dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        batch.fill_(-1)
+        torch.cuda.synchronize()
+        R.render_batch_into(batch.data_ptr(), h, w, ps, nb, frame_stride=h * w)
+        c.sync()
+        got = batch.cpu().numpy()
+        for f in range(nb):
+            assert int((got[f] != want).sum()) == 0, (rep, f)
+    # and a single frame again after the batch
+    out.fill_(-1)
+    torch.cuda.synchronize()
+    R.render_into(out.data_ptr(), h, w, ps)
+    c.sync()
+    assert int((out.cpu().numpy() != want).sum()) == 0
     c.close()
 
 

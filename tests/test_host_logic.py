@@ -89,6 +89,20 @@ def test_wave_state_machine_matches_oracle(scene, h, w):
     assert "diff_vs_simple 0" in pers
 
 
+def test_tile_queue_protocol_on_the_cpu():
+    """tools/queue_check drives the pooled kernel's ticket arithmetic (the __host__ __device__ functions of
+    rt_device.hpp: shards = strips of tile columns, deep-tile pieces, multi-tile tickets, static first tickets,
+    stealing from the other shards' counters) with emulated waves in random interleavings: every pixel slot of
+    every tile of every frame must be handed out exactly once."""
+    exe = os.path.join(ROOT, "build", "queue_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "build/queue_check"], cwd=ROOT, check=True)
+    for seed in (1, 2):
+        out = subprocess.run([exe, "1500", str(seed)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "random cases" in out.stdout and "passed" in out.stdout
+
+
 def test_reference_harness_builds_against_our_header():
     """/root/reference/futhark/main.c must compile and link unmodified (build container only)."""
     if not os.path.exists("/root/reference/futhark/main.c"):

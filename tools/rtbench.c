@@ -150,6 +150,15 @@ int main(int argc, char **argv) {
          (double)st[0] / t_kernel * 1e-6);
   printf("Algorithmic bandwidth: %.1f GB/s = %.3f of the 8000 GB/s HBM3E roofline\n", bytes_alg / t_kernel * 1e-9,
          bytes_alg / t_kernel * 1e-9 / 8000.0);
+  {
+    /* the last timed frame's pixels: c = c * 31 + pixel (SURVEY.md 8c's convenience checksums) */
+    int32_t *host = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
+    CHECK(ctx, rt_copy_to_host(ctx, host, img, (int64_t)sizeof(int32_t) * h * w));
+    uint32_t cs = 0;
+    for (long i = 0; i < (long)h * w; i++) cs = cs * 31u + (uint32_t)host[i];
+    printf("Checksum: %08x\n", cs);
+    free(host);
+  }
 
   }
   if (batch > 1 && parts == 1) {
