@@ -295,7 +295,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   // tiles per ticket: one ticket counter saturates at ~88 draws per microsecond, which batches and large frames reach
   p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : ((nframes > 1 || p.nchunks >= 32768) ? 2 : 0);
   // one ticket counter and one strip of tile columns per XCD (workgroup b runs on XCD b % 8)
-  p.nshards = (ctx->xcd_queues && nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  // (measured: a 1000x1000 frame is 3-6 % slower with shards -- its few deepest tiles, the ones handed out in pieces, are
+  // not spread evenly over the strips -- a 4000x4000 one 1.7x faster)
+  const bool shards = ctx->xcd_queues < 0 ? p.nchunks >= 32768 : ctx->xcd_queues != 0;
+  p.nshards = (shards && nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
   p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
@@ -512,7 +515,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   } else if (k == "deep_split") {
     ctx->deep_split = std::min(3, std::max(0, v));
   } else if (k == "xcd_queues") {
-    ctx->xcd_queues = v != 0;
+    ctx->xcd_queues = v < 0 ? -1 : (v != 0);
   } else if (k == "tpt_log2") {
     if (v < -1 || v > 4) return fail(ctx, "tpt_log2 must be -1 (auto) or 0..4");
     ctx->tpt_log2 = v;
@@ -874,7 +877,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.queue = ctx->queue_dev;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
   p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (p.nchunks >= 32768 ? 2 : 0);
-  p.nshards = (ctx->xcd_queues && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  p.nshards = ((ctx->xcd_queues < 0 ? p.nchunks >= 32768 : ctx->xcd_queues != 0) && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
   p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;

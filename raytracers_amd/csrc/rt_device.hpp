@@ -45,25 +45,33 @@ __host__ __device__ inline int shard_tile(const Shard &sh, int k, int tiles_x) {
   const int r = k / sh.sw;
   return r * tiles_x + sh.x0 + (k - r * sh.sw);
 }
-// Tickets of a shard with `npos` positions (tiles x frames): its first n_split positions (the deepest tiles of
-// the order) are handed out in 2^ds pieces each, the others 2^tpt positions per ticket.
-__host__ __device__ inline unsigned shard_tickets(unsigned npos, unsigned n_split, int ds, int tpt) {
-  return (n_split << ds) + ((npos - n_split + (1u << tpt) - 1u) >> tpt);
+// Tickets of a shard with `npos` positions (tiles x frames), whose first n_deep positions are deep tiles (waves that
+// draw one do not refill until it is finished): the first n_split <= n_deep of them (the deepest tiles of the order) are
+// handed out in 2^ds pieces each, the other deep tiles one per ticket (several to one wave would be traced one after
+// the other), the rest 2^tpt positions per ticket.
+__host__ __device__ inline unsigned shard_tickets(unsigned npos, unsigned n_split, unsigned n_deep, int ds, int tpt) {
+  return (n_split << ds) + (n_deep - n_split) + ((npos - n_deep + (1u << tpt) - 1u) >> tpt);
 }
 // ticket t < shard_tickets(...) -> the pixels it covers, as [q_next, q_end) in units of (position * 64 + pixel in tile)
 struct TicketSpan { unsigned q_next, q_end; };
-__host__ __device__ inline TicketSpan ticket_span(unsigned t, unsigned seg, unsigned npos, unsigned n_split, int ds, int tpt) {
+__host__ __device__ inline TicketSpan ticket_span(unsigned t, unsigned seg, unsigned npos, unsigned n_split, unsigned n_deep, int ds, int tpt) {
   TicketSpan sp;
   if (t < (n_split << ds)) {
     const unsigned piece = 64u >> ds;
     sp.q_next = (seg + (t >> ds)) * 64u + (t & ((1u << ds) - 1u)) * piece;
     sp.q_end = sp.q_next + piece;
-  } else {
-    const unsigned k0 = n_split + ((t - (n_split << ds)) << tpt);
-    const unsigned k1 = k0 + (1u << tpt) < npos ? k0 + (1u << tpt) : npos;
-    sp.q_next = (seg + k0) * 64u;
-    sp.q_end = (seg + k1) * 64u;
+    return sp;
   }
+  t -= n_split << ds;
+  if (t < n_deep - n_split) {
+    sp.q_next = (seg + n_split + t) * 64u;
+    sp.q_end = sp.q_next + 64u;
+    return sp;
+  }
+  const unsigned k0 = n_deep + ((t - (n_deep - n_split)) << tpt);
+  const unsigned k1 = k0 + (1u << tpt) < npos ? k0 + (1u << tpt) : npos;
+  sp.q_next = (seg + k0) * 64u;
+  sp.q_end = (seg + k1) * 64u;
   return sp;
 }
 
@@ -95,11 +103,11 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
   for (;;) {   // until a shard yields a ticket or all have run dry
     const int sh = queue_shard(state);
     const Shard s = shard_of(sh, c.ns_log2, c.tiles_x, c.tiles_y);
-    const int ndeep = queue_ndeep(c, sh);
+    const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
+    const int ndeep = queue_ndeep(c, sh);                // (<= the shard's tiles: a position of its class table)
     const int cap = (int)(c.home_waves >> (5 + c.ds));   // the pieces may occupy a 32nd of the shard's home waves
     const unsigned n_split = c.ds > 0 ? (unsigned)(ndeep < cap ? ndeep : cap) : 0u;
-    const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
-    const unsigned tickets = shard_tickets(npos, n_split, c.ds, c.tpt);
+    const unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
     unsigned t = 0;
     bool got = false;
     if (state & kQueueFirst) {
@@ -111,7 +119,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
       got = t < tickets;
     }
     if (got) {
-      *sp = ticket_span(t, (unsigned)s.seg, npos, n_split, c.ds, c.tpt);
+      *sp = ticket_span(t, (unsigned)s.seg, npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
       return true;
     }
     state |= 0x100u << sh;

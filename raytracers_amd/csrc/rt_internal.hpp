@@ -40,7 +40,7 @@ struct rt_context {
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
   int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
-  int xcd_queues = 0;       // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp)
+  int xcd_queues = -1;      // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp); -1: frames of >= 32768 tiles
   int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers (-1: 2 for batches and frames of >= 32768 tiles, else 0)
   int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last

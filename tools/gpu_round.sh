@@ -8,14 +8,23 @@ export TMPDIR=/tmp
 TAG=${1:-round}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
+# env: SKIP_TESTS=1 (none) | quick (a subset); SKIP_PEAK=1 keeps profiles/issue_peak.json (the microbenchmark does not depend
+# on the kernel sources); PMC_GDS="0 4" adds the quarter-size launches of --protocol lanes to the PMC passes
 if [ -z "$SKIP_TESTS" ]; then
   timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> $OUT/pytest_gpu.log
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+elif [ "$SKIP_TESTS" = quick ]; then
+  timeout 400 python -m pytest tests -m gpu -x -q -k "golden_500 or tile_queue_layouts or bench_line_contract or irreg_4000 or big_2000 or reference_harness" > $OUT/pytest_gpu.log 2>&1
+  echo "pytest (subset) exit $?" >> $OUT/pytest_gpu.log
 fi
-bash tools/gpu_issue_peak.sh gpurun_out/$TAG/issue_peak.txt > /dev/null 2>&1
-python tools/make_issue_peak_json.py $OUT/issue_peak.txt > $OUT/issue_peak.json
-bash tools/gpu_pmc.sh $TAG/pmc "0 4" "rgbbox irreg" > $OUT/pmc.log 2>&1
+[ "$SKIP_TESTS" != 1 ] && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+if [ -z "$SKIP_PEAK" ]; then
+  bash tools/gpu_issue_peak.sh gpurun_out/$TAG/issue_peak.txt > /dev/null 2>&1
+  python tools/make_issue_peak_json.py $OUT/issue_peak.txt > $OUT/issue_peak.json
+else
+  cp profiles/issue_peak.json $OUT/issue_peak.json
+fi
+bash tools/gpu_pmc.sh $TAG/pmc "${PMC_GDS:-0}" "rgbbox irreg" > $OUT/pmc.log 2>&1
 python tools/make_pmc_json.py $OUT/pmc $OUT/issue_peak.json > $OUT/pmc.json 2> $OUT/pmc_json.err
 cp $OUT/pmc.json $OUT/issue_peak.json profiles/        # on the GPU box only: the bench runs below read them
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err

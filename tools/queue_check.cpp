@@ -106,7 +106,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
     const int ndeep = queue_ndeep(qc, s);
     const int cap = static_cast<int>(qc.home_waves >> (5 + c.ds));
     const unsigned n_split = c.ds > 0 ? static_cast<unsigned>(ndeep < cap ? ndeep : cap) : 0u;
-    const unsigned tk = shard_tickets(static_cast<unsigned>(sh.ntiles) * c.nframes, n_split, c.ds, c.tpt);
+    const unsigned tk = shard_tickets(static_cast<unsigned>(sh.ntiles) * c.nframes, n_split, static_cast<unsigned>(ndeep), c.ds, c.tpt);
     const unsigned dyn = tk > qc.q_static ? tk - qc.q_static : 0u;
     if (dyn == 0 && draws[static_cast<size_t>(s)] != 0) { std::printf("counter of an all-static shard was drawn from\n"); return 1; }
     if (dyn != 0 && (draws[static_cast<size_t>(s)] < dyn || draws[static_cast<size_t>(s)] > dyn + static_cast<unsigned>(c.waves))) {
