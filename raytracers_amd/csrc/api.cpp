@@ -297,8 +297,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   // one ticket counter and one strip of tile columns per XCD (workgroup b runs on XCD b % 8)
   // (measured: a 1000x1000 frame is 3-6 % slower with shards -- its few deepest tiles, the ones handed out in pieces, are
   // not spread evenly over the strips -- a 4000x4000 one 1.7x faster)
-  const bool shards = ctx->xcd_queues < 0 ? p.nchunks >= 32768 : ctx->xcd_queues != 0;
-  p.nshards = (shards && nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  const int xq = ctx->xcd_queues < 0 ? (p.nchunks >= 32768 ? 1 : 0) : ctx->xcd_queues;
+  p.nshards = (xq && nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  p.interleave = p.nshards > 1 && xq == 2;
+  const int order_shards = p.interleave ? 1 : p.nshards;   // layout of the view's order table
   p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
@@ -315,7 +317,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       for (auto &o : ps->orders)
         if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
             o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks &&
-            o.nshards == p.nshards)
+            o.nshards == order_shards)
           to = &o;
       if (!to) {
         if (ps->orders.size() >= 8) {   // bounded: forget the oldest view
@@ -328,7 +330,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         o.h = h; o.w = w; o.rows_per_tile = rows_per_tile; o.part = part; o.nparts = nparts; o.max_depth = max_depth;
         std::memcpy(o.cam, &p.cam, sizeof o.cam);
         o.ntiles = p.nchunks;
-        o.nshards = p.nshards;
+        o.nshards = order_shards;
         RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
         RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(o.ntiles))));
         RT_HIP(ctx, hipMemsetAsync(o.cost, 0, sizeof(int) * static_cast<size_t>(o.ntiles), ctx->stream));
@@ -406,7 +408,7 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   rtk::warm_build_kernels();
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
   // (test aids: the whole suite under the other queue layouts)
-  if (const char *v = std::getenv("RT_XCD_QUEUES")) ctx->xcd_queues = std::atoi(v) != 0;
+  if (const char *v = std::getenv("RT_XCD_QUEUES")) ctx->xcd_queues = std::max(-1, std::min(2, std::atoi(v)));
   if (const char *v = std::getenv("RT_TPT_LOG2")) ctx->tpt_log2 = std::max(-1, std::min(4, std::atoi(v)));
   if (const char *v = std::getenv("RT_STATIC_FIRST")) ctx->static_first = std::atoi(v) != 0;
   *out = ctx.release();
@@ -515,7 +517,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   } else if (k == "deep_split") {
     ctx->deep_split = std::min(3, std::max(0, v));
   } else if (k == "xcd_queues") {
-    ctx->xcd_queues = v < 0 ? -1 : (v != 0);
+    if (v < -1 || v > 2) return fail(ctx, "xcd_queues must be -1 (auto), 0 (one counter), 1 (a strip of tile columns per counter) or 2 (counters take turns)");
+    ctx->xcd_queues = v;
   } else if (k == "tpt_log2") {
     if (v < -1 || v > 4) return fail(ctx, "tpt_log2 must be -1 (auto) or 0..4");
     ctx->tpt_log2 = v;
@@ -877,7 +880,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.queue = ctx->queue_dev;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
   p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (p.nchunks >= 32768 ? 2 : 0);
-  p.nshards = ((ctx->xcd_queues < 0 ? p.nchunks >= 32768 : ctx->xcd_queues != 0) && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  const int xq = ctx->xcd_queues < 0 ? (p.nchunks >= 32768 ? 1 : 0) : ctx->xcd_queues;
+  p.nshards = (xq && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+  p.interleave = p.nshards > 1 && xq == 2;
   p.static_first = ctx->static_first;
   p.lds_nodes = pl.lds_nodes; p.lds_sph = pl.lds_sph;
   p.smax = pl.smax; p.lmax = pl.lmax;
@@ -891,7 +896,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
     // use the adaptive order of the matching view if one exists (read-only here)
     for (auto &o : ps->orders)
       if (o.h == h && o.w == w && o.part == 0 && o.nparts == 1 && o.max_depth == max_depth && o.valid &&
-          ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == p.nshards) {
+          ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
         p.order = o.order;
         p.deep_class = ctx->deep_class;
         p.deep_split = ctx->deep_split;

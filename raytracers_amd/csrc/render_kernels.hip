@@ -140,11 +140,9 @@ __device__ __forceinline__ int lane_rank_from(unsigned long long m, int base) { 
 
 // ds_add_u32 executed by exactly the lanes of a 64-bit mask held in SGPRs (no VALU compare, no branch): the
 // exec mask is narrowed around the one instruction and restored.
-// (the address is lds_byte_addr + 512: the slot counters sit 512 bytes into a wave's LDS region, and the instruction's
-// offset field saves keeping a second base)
-__device__ __forceinline__ void lds_add_masked_512(unsigned long long m, int lds_byte_addr, int v) {
+__device__ __forceinline__ void lds_add_masked(unsigned long long m, int lds_byte_addr, int v) {
   unsigned long long saved;
-  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3 offset:512\n\ts_mov_b64 exec, %0"
+  asm volatile("s_and_saveexec_b64 %0, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0"
                : "=&s"(saved)
                : "s"(m), "v"(lds_byte_addr), "v"(v)
                : "memory");
@@ -158,40 +156,6 @@ __device__ __forceinline__ void queue_leave(const KParams &p, unsigned nwaves, i
     for (int s = 0; s < kMaxShards; ++s) atomicExch(&p.queue[kQueueStride * s], 0u);
     atomicExch(&p.queue[kQueueExit], 0u);
   }
-}
-
-// 16-byte LDS read at a byte address.  The pooled kernel has no static LDS, so its dynamic LDS starts at address 0
-// (launch_pooled_t checks the kernel's static LDS size): a node record's quarter is at (plane offset + node * 16) with no base.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 lds_read16(int lds_byte_addr) {
-  const v4f v = *reinterpret_cast<const __attribute__((address_space(3))) v4f *>((unsigned)lds_byte_addr);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-
-// sbase + 4 * (# set bits of m below this lane): the LDS byte address of this lane's append slot in a list whose
-// end (wave-uniform, in an SGPR) is sbase
-__device__ __forceinline__ int rank_addr(unsigned long long m, int sbase) {
-  const int r = lane_rank(m);
-  int out;
-  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(out) : "v"(r), "s"(sbase));
-  return out;
-}
-
-// Four ds_write_b32, each executed by exactly the lanes of its 64-bit mask (held in SGPRs): the appends of a BOX
-// operation -- left child to the box stack / the leaf list, right child likewise -- without select chains or a dump
-// address.  The masks are subsets of the (full) exec mask the render loop runs under.
-__device__ __forceinline__ void lds_store4_masked(unsigned long long m0, int a0, unsigned long long m1, int a1, unsigned v01,
-                                                  unsigned long long m2, int a2, unsigned long long m3, int a3, unsigned v23) {
-  unsigned long long saved;
-  asm volatile("s_mov_b64 %0, exec\n\t"
-               "s_mov_b64 exec, %1\n\tds_write_b32 %5, %9\n\t"
-               "s_mov_b64 exec, %2\n\tds_write_b32 %6, %9\n\t"
-               "s_mov_b64 exec, %3\n\tds_write_b32 %7, %10\n\t"
-               "s_mov_b64 exec, %4\n\tds_write_b32 %8, %10\n\t"
-               "s_mov_b64 exec, %0"
-               : "=&s"(saved)
-               : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(v01), "v"(v23)
-               : "memory");
 }
 
 template <int THREADS, bool STATS>
@@ -400,7 +364,7 @@ template <int THREADS, bool ALL_LDS, bool STATS>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = uni(threadIdx.x >> 6);   // (an SGPR: the wave's LDS bases are then scalar)
+  const int wave = threadIdx.x >> 6;
   const int plane = p.lds_nodes;          // float4 per node plane
   const int sph_base = 4 * plane;
   // per-wave region: key[64] (u64) | cnt[64] | dump[4] | rays[ray_planes][64] float4 | box stack[capb] | leaf list[capl]
@@ -408,16 +372,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   unsigned *const wbase = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + wave * per_wave_dw;
   unsigned long long *const wkey = reinterpret_cast<unsigned long long *>(wbase);
   int *const wcnt = reinterpret_cast<int *>(wbase + 128);
-  // (wbase + 192: four spare dwords)
+  unsigned *const wdump = wbase + 192;    // where lanes with nothing to append write
   float4 *const wray = reinterpret_cast<float4 *>(wbase + kPooledWaveFixedDw);   // [0..63] {o.xyz, a}  [64..127] {1/d, 0}  ([128..191] {d, 0})
   unsigned *const wbox = wbase + kPooledWaveFixedDw + 256 * p.ray_planes;
   unsigned *const wleaf = wbox + p.capb;
-  // the same as 32-bit LDS byte addresses in SGPRs (what the BOX operations compute with)
-  const int wbase_b = uni((int)(size_t)wbase);
-  static_assert(kPooledWaveFixedDw >= 192, "hit keys (512 B), then the slot counters at byte 512: lds_add_masked_512");
-  const int wray_b = wbase_b + 4 * kPooledWaveFixedDw;
-  const int wbox_b = wray_b + 1024 * p.ray_planes, wleaf_b = wbox_b + 4 * p.capb;
-  const int p16 = 16 * plane;             // bytes per node plane
   const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(p.nodes64, (unsigned)p.n_nodes * 64u);
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(p.sph, (unsigned)p.n_sph * 16u);
   const __amdgpu_buffer_rsrc_t rs_col = make_rsrc(p.col, (unsigned)p.n_sph * 16u);
@@ -466,6 +424,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   auto queue_const = [&]() {   // (built where it is used: nothing of it stays live across the render loop)
     QueueConst qc;
     qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.nchunks / p.tiles_x; qc.nframes = p.nframes;
+    qc.interleave = p.interleave;
     qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.ntiles = p.nchunks;
     qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
     qc.home_waves = nwaves >> ns_log2;                       // the same for every shard (the grid is a multiple of nshards)
@@ -608,9 +567,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 if (p.cams != nullptr) q_cam = p.cams[f];
               }
               const QueueConst qc = queue_const();
-              const Shard q_s = shard_of(queue_shard(q_state), ns_log2, qc.tiles_x, qc.tiles_y);   // the shard the ticket came from
+              const Shard q_s = shard_of(queue_geo_shard(qc, q_state), queue_geo_log2(qc), qc.tiles_x, qc.tiles_y);   // the shard the ticket came from
               q_tile = p.order != nullptr ? p.order[t] : shard_tile(q_s, (int)t - q_s.seg, p.tiles_x);   // uniform (scalar) load
-              if (deep_on && (int)t - q_s.seg < queue_ndeep(qc, queue_shard(q_state))) {
+              if (deep_on && (int)t - q_s.seg < queue_ndeep(qc, queue_geo_shard(qc, q_state))) {
                 hold = true;
                 __builtin_amdgcn_s_setprio(3);
               }
@@ -720,15 +679,17 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         nbox = uni(FULL ? nbox - 64 : 0);
         const int sl4 = (int)(item & 0xfcu);
         const int ni16 = (int)((item >> 4) & 0xfffffff0u);   // node index * 16: its byte offset within a plane
-        const float4 ra = lds_read16(wray_b + 4 * sl4), ri = lds_read16(wray_b + 4 * sl4 + 1024);
+        const float4 *const rayp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wray) + 4 * sl4);
+        const float4 ra = rayp[0], ri = rayp[64];
         Ray q;
         q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
         q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
         float4 q0, q1, q2, q3;
         {
-          const int lo16 = ALL_LDS ? ni16 : (ni16 < p16 ? ni16 : 0);
-          q0 = lds_read16(lo16); q1 = lds_read16(lo16 + p16); q2 = lds_read16(lo16 + 2 * p16); q3 = lds_read16(lo16 + 3 * p16);
-          if (!ALL_LDS && ni16 >= p16) {
+          const int lo16 = ALL_LDS ? ni16 : (ni16 < 16 * plane ? ni16 : 0);
+          const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
+          q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
+          if (!ALL_LDS && ni16 >= 16 * plane) {
             q0 = buf_load16(rs_nodes, ni16 * 4);
             q1 = buf_load16(rs_nodes, ni16 * 4 + 16);
             q2 = buf_load16(rs_nodes, ni16 * 4 + 32);
@@ -749,17 +710,19 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         // children's ranks start at the left children's count: mbcnt's addend).  ONE store per child: to the box
         // stack, to the leaf list, or to the dump dword
         const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-        // (list ends as LDS byte addresses -- the low 32 bits of the flat addresses -- in SGPRs; the right children's
-        // ranks start behind the left children's: a scalar add)
-        const int b_box = wbox_b + 4 * nbox, b_leaf = wleaf_b + 4 * nleaf;
-        lds_store4_masked(m_inl, rank_addr(m_inl, b_box), m_lfl, rank_addr(m_lfl, b_leaf), (unsigned)cl8 | (unsigned)sl4,
-                          m_inr, rank_addr(m_inr, b_box + 4 * c_inl), m_lfr, rank_addr(m_lfr, b_leaf + 4 * c_lfl), (unsigned)cr8 | (unsigned)sl4);
+        const int dump = (int)(size_t)(wdump);   // LDS byte address (low 32 bits of the flat address)
+        const int b_box = (int)(size_t)(wbox + nbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+        const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+        const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * lane_rank_from(m_inr, c_inl)),
+                                 b_leaf + 4 * lane_rank_from(m_lfr, c_lfl));
+        lds_store(a_l, (unsigned)cl8 | (unsigned)sl4);
+        lds_store(a_r, (unsigned)cr8 | (unsigned)sl4);
         nbox = uni(nbox + c_inl + __popcll(m_inr));
         nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
         // outstanding inner-node items of the slot: one consumed, k in {0, 1, 2} appended.  Only items with k != 1
         // touch the counter (same-address LDS atomics serialise): the ds_add runs under exactly their lane mask.
         const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
-        lds_add_masked_512(m_two | m_none, wbase_b + sl4, sel_mask(m_two, -1, 1));
+        lds_add_masked(m_two | m_none, (int)(size_t)wcnt + sl4, sel_mask(m_two, -1, 1));
       };
       // ---- BOX2: at most 32 items, TWO lanes and TWO tree levels each.  A wave with a nearly empty stack is on some
       // frame's critical path (a long bounce chain advances one operation per tree level): lane 2k handles the LEFT child
@@ -776,7 +739,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         nbox = uni(0);
         const int sl4 = (int)(item & 0xfcu);
         const int ni16 = (int)((item >> 4) & 0xfffffff0u);
-        const float4 ra = lds_read16(wray_b + 4 * sl4), ri = lds_read16(wray_b + 4 * sl4 + 1024);
+        const float4 *const rayp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wray) + 4 * sl4);
+        const float4 ra = rayp[0], ri = rayp[64];
         Ray q;
         q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
         q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
@@ -784,11 +748,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         float4 lo, hi;
         int ref;
         {
-          const bool res = ALL_LDS || ni16 < p16;
+          const bool res = ALL_LDS || ni16 < 16 * plane;
           const int lo16 = res ? ni16 : 0;
-          lo = lds_read16(lo16 + 2 * role * p16);
-          hi = lds_read16(lo16 + (2 * role + 1) * p16);
-          ref = f2i(lds_read16(lo16 + role * p16).w);
+          const char *const np = reinterpret_cast<const char *>(smem) + lo16;
+          lo = *reinterpret_cast<const float4 *>(np + 32 * role * plane);
+          hi = *reinterpret_cast<const float4 *>(np + (32 * role + 16) * plane);
+          ref = f2i(reinterpret_cast<const float4 *>(np + 16 * role * plane)->w);
           if (!ALL_LDS && !res) {
             lo = buf_load16(rs_nodes, ni16 * 4 + 32 * role);
             hi = buf_load16(rs_nodes, ni16 * 4 + 32 * role + 16);
@@ -802,9 +767,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int ci16 = pass ? (int)(((unsigned)ref >> 4) & 0xfffffff0u) : 0;
         float4 q0, q1, q2, q3;
         {
-          const int lo16 = ALL_LDS ? ci16 : (ci16 < p16 ? ci16 : 0);
-          q0 = lds_read16(lo16); q1 = lds_read16(lo16 + p16); q2 = lds_read16(lo16 + 2 * p16); q3 = lds_read16(lo16 + 3 * p16);
-          if (!ALL_LDS && ci16 >= p16) {
+          const int lo16 = ALL_LDS ? ci16 : (ci16 < 16 * plane ? ci16 : 0);
+          const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
+          q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
+          if (!ALL_LDS && ci16 >= 16 * plane) {
             q0 = buf_load16(rs_nodes, ci16 * 4);
             q1 = buf_load16(rs_nodes, ci16 * 4 + 16);
             q2 = buf_load16(rs_nodes, ci16 * 4 + 32);
@@ -822,15 +788,19 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const unsigned long long m_lfl = (m_pass & m_ln) | m_cleaf, m_lfr = m_pass & m_rn;
         if (STATS) n_box += __popcll(m_pass & ~m_ln & (1ull << lane)) + __popcll(m_pass & ~m_rn & (1ull << lane));
         const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
-        const int b_box = wbox_b, b_leaf = wleaf_b + 4 * nleaf;
-        lds_store4_masked(m_inl, rank_addr(m_inl, b_box), m_lfl, rank_addr(m_lfl, b_leaf), (unsigned)sel_mask(m_cleaf, cl8, ref) | (unsigned)sl4,
-                          m_inr, rank_addr(m_inr, b_box + 4 * c_inl), m_lfr, rank_addr(m_lfr, b_leaf + 4 * c_lfl), (unsigned)cr8 | (unsigned)sl4);
+        const int dump = (int)(size_t)(wdump);
+        const int b_box = (int)(size_t)(wbox), b_leaf = (int)(size_t)(wleaf + nleaf);
+        const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+        const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * lane_rank_from(m_inr, c_inl)),
+                                 b_leaf + 4 * lane_rank_from(m_lfr, c_lfl));
+        lds_store(a_l, (unsigned)sel_mask(m_cleaf, cl8, ref) | (unsigned)sl4);
+        lds_store(a_r, (unsigned)cr8 | (unsigned)sl4);
         nbox = uni(c_inl + __popcll(m_inr));
         nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
         // the slot's counter of outstanding inner-node items: this lane's appended inner grandchildren, minus the item
         // itself (counted once, by the pair's even lane)
         const int d = sel_mask(m_inl, 0, 1) + sel_mask(m_inr, 0, 1) - sel_mask(bal(act & (role == 0)), 0, 1);
-        lds_add_masked_512(bal(d != 0), wbase_b + sl4, d);
+        lds_add_masked(bal(d != 0), (int)(size_t)wcnt + sl4, d);
       };
       if (nbox >= 64) box(std::true_type{});
       else if (nbox <= 32 && p.box2) box2();
@@ -1024,12 +994,6 @@ template <int THREADS, bool ALL_LDS, bool STATS>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
   auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS>;
-  // the kernel addresses its node planes from LDS byte 0 (lds_read16): it must not own static LDS
-  static const bool no_static_lds = [&] {
-    hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(kfn)) == hipSuccess && a.sharedSizeBytes == 0;
-  }();
-  if (!no_static_lds) return hipErrorInvalidValue;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();

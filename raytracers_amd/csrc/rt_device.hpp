@@ -79,6 +79,7 @@ __host__ __device__ inline TicketSpan ticket_span(unsigned t, unsigned seg, unsi
 // CPU).  `fetch_add(shard)` returns the shard's counter before its increment.
 struct QueueConst {
   int ns_log2, tiles_x, tiles_y, nframes;
+  int interleave;            // 1: the shards are not strips but every (1 << ns_log2)-th ticket of ONE queue over all tiles (geometry and tables of a single shard)
   int ds, tpt;               // deep_split, tpt_log2
   int ntiles;                // all shards' tiles: the class tables sit at order[ntiles + kOrderTableDw * shard]
   const int *order;          // nullptr: no tables
@@ -93,6 +94,9 @@ __host__ __device__ inline unsigned queue_state_init(int home_shard, bool static
   return (unsigned)home_shard | (static_first ? kQueueFirst : 0u);
 }
 __host__ __device__ inline int queue_shard(unsigned state) { return (int)(state & 7u); }
+// the shard whose geometry (strip, segment, class table) the ticket in hand belongs to
+__host__ __device__ inline int queue_geo_shard(const QueueConst &c, unsigned state) { return c.interleave ? 0 : queue_shard(state); }
+__host__ __device__ inline int queue_geo_log2(const QueueConst &c) { return c.interleave ? 0 : c.ns_log2; }
 // deep tiles at the head of a shard's segment (0: none / feature off)
 __host__ __device__ inline int queue_ndeep(const QueueConst &c, int shard) {
   return (c.order != nullptr && c.deep_class > 0) ? c.order[c.ntiles + kOrderTableDw * shard + c.deep_class] : 0;
@@ -102,12 +106,16 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
   const unsigned all = ((1u << (1 << c.ns_log2)) - 1u) << 8;
   for (;;) {   // until a shard yields a ticket or all have run dry
     const int sh = queue_shard(state);
-    const Shard s = shard_of(sh, c.ns_log2, c.tiles_x, c.tiles_y);
+    const int geo = c.interleave ? 0 : sh;
+    const Shard s = shard_of(geo, queue_geo_log2(c), c.tiles_x, c.tiles_y);
     const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
-    const int ndeep = queue_ndeep(c, sh);                // (<= the shard's tiles: a position of its class table)
-    const int cap = (int)(c.home_waves >> (5 + c.ds));   // the pieces may occupy a 32nd of the shard's home waves
+    const int ndeep = queue_ndeep(c, geo);               // (<= the shard's tiles: a position of its class table)
+    // the pieces may occupy a 32nd of the waves the queue (strips: the shard) serves
+    const int cap = (int)((c.interleave ? c.home_waves << c.ns_log2 : c.home_waves) >> (5 + c.ds));
     const unsigned n_split = c.ds > 0 ? (unsigned)(ndeep < cap ? ndeep : cap) : 0u;
-    const unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
+    unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
+    // interleaved: this counter's tickets are the queue's tickets sh, sh + n, sh + 2 n, ... (n counters)
+    if (c.interleave) tickets = (tickets + (1u << c.ns_log2) - 1u - (unsigned)sh) >> c.ns_log2;
     unsigned t = 0;
     bool got = false;
     if (state & kQueueFirst) {
@@ -119,6 +127,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
       got = t < tickets;
     }
     if (got) {
+      if (c.interleave) t = (t << c.ns_log2) + (unsigned)sh;
       *sp = ticket_span(t, (unsigned)s.seg, npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
       return true;
     }
@@ -155,7 +164,8 @@ struct KParams {
   unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
   // persistent family
   unsigned *queue;       // [kQueueDwords] ticket counter of shard s at [kQueueStride * s], waves that have left at [kQueueExit]; all zero between launches
-  int nshards;           // 1, or 8 (pooled family, one frame per launch): one ticket counter and one strip of tile columns per XCD
+  int nshards;           // 1, or 8 (pooled family, one frame per launch): one ticket counter per XCD ...
+  int interleave;        // ... 0: and one strip of tile columns per counter; 1: the counters take turns over ONE queue (order table of a single shard)
   int static_first;      // pooled family: a wave's first ticket is its own number within its home shard (no atomic: no ramp at launch)
   int nchunks;           // 8x8 tiles in this part
   int lds_nodes;         // breadth-first node prefix staged in LDS

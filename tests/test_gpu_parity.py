@@ -392,11 +392,13 @@ def test_adaptive_tile_order_renders_every_pixel(R, scene, h, w, adaptive, deep_
     c.close()
 
 
-@pytest.mark.parametrize("xcd,tpt,static_first", [(1, -1, 1), (1, 0, 0), (1, 2, 1), (1, 4, 0), (0, 1, 1), (0, 3, 0), (0, -1, 0)])
+@pytest.mark.parametrize("xcd,tpt,static_first", [(1, -1, 1), (1, 0, 0), (1, 2, 1), (1, 4, 0), (0, 1, 1), (0, 3, 0), (0, -1, 0),
+                                                  (2, -1, 1), (2, 1, 0), (2, 3, 1)])
 @pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 1000, 1000), ("irreg", 40, 24)])
 def test_tile_queue_layouts_render_every_pixel(R, scene, h, w, xcd, tpt, static_first):
-    """The tile queue of the pooled family: one ticket counter and one strip of tile columns per XCD (xcd_queues) with
-    stealing, several tiles per ticket (tpt_log2), the waves' first tickets handed out without an atomic (static_first) --
+    """The tile queue of the pooled family: one ticket counter per XCD -- each with its own strip of tile columns
+    (xcd_queues=1) or taking turns over one queue (2) -- with stealing, several tiles per ticket (tpt_log2), the waves'
+    first tickets handed out without an atomic (static_first) --
     combined with the adaptive order, deep tiles and their pieces.  Frames 0..3 of a view (recording frame, then ordered
     ones), a part of a three-way row partition and a batch of three frames must each write every pixel (buffers poisoned)
     and stay bit-exact; the counters must come back to zero after every launch (the next launch relies on it)."""

@@ -18,17 +18,19 @@
 using namespace rtk;
 
 struct Cfg {
-  int tiles_x, tiles_y, ns_log2, nframes, ds, tpt, deep_class, waves, static_first;
+  int tiles_x, tiles_y, ns_log2, nframes, ds, tpt, deep_class, waves, static_first, interleave;
 };
 
 static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
-  const int ns = 1 << c.ns_log2;
+  const int ns = 1 << c.ns_log2;                 // counters
+  const int gl2 = c.interleave ? 0 : c.ns_log2;  // log2 of the shards of the GEOMETRY (strips, order table)
+  const int gs = 1 << gl2;
   const int ntiles = c.tiles_x * c.tiles_y;
   // a synthetic order table: the identity within each strip + class tables with random deep counts
   std::vector<int> order(static_cast<size_t>(order_table_ints(ntiles)), 0);
   std::vector<int> seen_tile(static_cast<size_t>(ntiles), 0);
-  for (int s = 0; s < ns; ++s) {
-    const Shard sh = shard_of(s, c.ns_log2, c.tiles_x, c.tiles_y);
+  for (int s = 0; s < gs; ++s) {
+    const Shard sh = shard_of(s, gl2, c.tiles_x, c.tiles_y);
     for (int k = 0; k < sh.ntiles; ++k) {
       const int tile = shard_tile(sh, k, c.tiles_x);
       if (tile < 0 || tile >= ntiles) { std::printf("tile out of range\n"); return 1; }
@@ -49,7 +51,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
 
   QueueConst qc;
   qc.ns_log2 = c.ns_log2; qc.tiles_x = c.tiles_x; qc.tiles_y = c.tiles_y; qc.nframes = c.nframes;
-  qc.ds = c.ds; qc.tpt = c.tpt; qc.ntiles = ntiles;
+  qc.ds = c.ds; qc.tpt = c.tpt; qc.ntiles = ntiles; qc.interleave = c.interleave;
   const bool deep_on = c.nframes == 1 && c.deep_class > 0;
   qc.order = deep_on ? order.data() : nullptr; qc.deep_class = c.deep_class;
   qc.home_waves = static_cast<unsigned>(c.waves >> c.ns_log2);
@@ -88,7 +90,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
     tickets_taken++;
     if (sp.q_end <= sp.q_next || sp.q_end > cover.size()) { std::printf("bad span [%u, %u) of %zu\n", sp.q_next, sp.q_end, cover.size()); return 1; }
     // the span lies in the shard the wave is drawing from
-    const Shard sh = shard_of(queue_shard(W.state), c.ns_log2, c.tiles_x, c.tiles_y);
+    const Shard sh = shard_of(queue_geo_shard(qc, W.state), gl2, c.tiles_x, c.tiles_y);
     if ((sp.q_next >> 6) < static_cast<unsigned>(sh.seg) * 1u || ((sp.q_end - 1) >> 6) >= static_cast<unsigned>(sh.seg + sh.ntiles * c.nframes)) {
       std::printf("span outside its shard\n");
       return 1;
@@ -102,11 +104,13 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
     if (!cover[i]) { std::printf("pixel slot %zu never handed out (cfg %d x %d ns %d nf %d ds %d tpt %d dc %d W %d sf %d)\n", i, c.tiles_x, c.tiles_y, ns, c.nframes, c.ds, c.tpt, c.deep_class, c.waves, c.static_first); return 1; }
   // counter draws: successes + at most one failure per wave per shard; none on a shard without dynamic tickets
   for (int s = 0; s < ns; ++s) {
-    const Shard sh = shard_of(s, c.ns_log2, c.tiles_x, c.tiles_y);
-    const int ndeep = queue_ndeep(qc, s);
-    const int cap = static_cast<int>(qc.home_waves >> (5 + c.ds));
+    const int geo = c.interleave ? 0 : s;
+    const Shard sh = shard_of(geo, gl2, c.tiles_x, c.tiles_y);
+    const int ndeep = queue_ndeep(qc, geo);
+    const int cap = static_cast<int>((c.interleave ? qc.home_waves << c.ns_log2 : qc.home_waves) >> (5 + c.ds));
     const unsigned n_split = c.ds > 0 ? static_cast<unsigned>(ndeep < cap ? ndeep : cap) : 0u;
-    const unsigned tk = shard_tickets(static_cast<unsigned>(sh.ntiles) * c.nframes, n_split, static_cast<unsigned>(ndeep), c.ds, c.tpt);
+    unsigned tk = shard_tickets(static_cast<unsigned>(sh.ntiles) * c.nframes, n_split, static_cast<unsigned>(ndeep), c.ds, c.tpt);
+    if (c.interleave) tk = (tk + static_cast<unsigned>(ns) - 1u - static_cast<unsigned>(s)) >> c.ns_log2;
     const unsigned dyn = tk > qc.q_static ? tk - qc.q_static : 0u;
     if (dyn == 0 && draws[static_cast<size_t>(s)] != 0) { std::printf("counter of an all-static shard was drawn from\n"); return 1; }
     if (dyn != 0 && (draws[static_cast<size_t>(s)] < dyn || draws[static_cast<size_t>(s)] > dyn + static_cast<unsigned>(c.waves))) {
@@ -114,8 +118,8 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
       return 1;
     }
   }
-  if (verbose) std::printf("ok: %dx%d tiles, %d shard(s), %d frame(s), ds %d, tpt %d, %d waves, static %d: %llu tickets\n", c.tiles_x, c.tiles_y, ns,
-                           c.nframes, c.ds, c.tpt, c.waves, c.static_first, tickets_taken);
+  if (verbose) std::printf("ok: %dx%d tiles, %d counter(s)%s, %d frame(s), ds %d, tpt %d, %d waves, static %d: %llu tickets\n", c.tiles_x, c.tiles_y, ns,
+                           c.interleave ? " taking turns" : (ns > 1 ? ", a strip each" : ""), c.nframes, c.ds, c.tpt, c.waves, c.static_first, tickets_taken);
   return 0;
 }
 
@@ -125,9 +129,10 @@ int main(int argc, char **argv) {
   std::mt19937 rng(seed);
   // the production shapes first
   const Cfg fixed[] = {
-      {125, 125, 0, 1, 2, 0, 3, 4096, 1},  {125, 125, 3, 1, 2, 0, 3, 4096, 1}, {125, 125, 0, 20, 2, 2, 3, 4096, 1},
-      {500, 500, 3, 1, 2, 2, 3, 4096, 1},  {500, 63, 3, 1, 2, 2, 3, 2048, 1},  {250, 250, 0, 1, 2, 2, 3, 4096, 0},
-      {1, 1, 0, 1, 2, 0, 3, 4096, 1},      {3, 2, 3, 1, 2, 0, 3, 64, 1},       {25, 25, 3, 1, 0, 0, 0, 1024, 1},
+      {125, 125, 0, 1, 2, 0, 3, 4096, 1, 0},  {125, 125, 3, 1, 2, 0, 3, 4096, 1, 0}, {125, 125, 0, 20, 2, 2, 3, 4096, 1, 0},
+      {500, 500, 3, 1, 2, 2, 3, 4096, 1, 0},  {500, 63, 3, 1, 2, 2, 3, 2048, 1, 0},  {250, 250, 0, 1, 2, 2, 3, 4096, 0, 0},
+      {1, 1, 0, 1, 2, 0, 3, 4096, 1, 0},      {3, 2, 3, 1, 2, 0, 3, 64, 1, 0},       {25, 25, 3, 1, 0, 0, 0, 1024, 1, 0},
+      {125, 125, 3, 1, 2, 0, 3, 4096, 1, 1},  {500, 500, 3, 1, 2, 1, 3, 4096, 1, 1}, {3, 2, 3, 1, 2, 0, 3, 64, 0, 1},
   };
   for (const Cfg &c : fixed)
     if (run(c, rng, true)) return 1;
@@ -142,6 +147,7 @@ int main(int argc, char **argv) {
     c.deep_class = static_cast<int>(rng() % 5);
     c.waves = 32 * (1 + static_cast<int>(rng() % 40));   // workgroups of 4 waves, a multiple of 8 workgroups
     c.static_first = static_cast<int>(rng() & 1);
+    c.interleave = (c.ns_log2 == 3 && (rng() & 1)) ? 1 : 0;
     if (run(c, rng, false)) {
       std::printf("FAILED case %d (seed %u)\n", i, seed);
       return 1;
