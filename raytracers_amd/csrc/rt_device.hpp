@@ -15,12 +15,16 @@ constexpr int pooled_wave_dw(int ray_planes, int capb, int capl) { return kPoole
 
 // ---- the tile queue of the persistent families --------------------------------------------------
 // Tickets are drawn with returning device-scope atomics; one word saturates at ~88 draws per microsecond
-// (MI355X_MICROARCH.md, "dequeue"), which a 4000x4000 frame's 250 000 tiles reach.  So the queue is SHARDED:
-// nshards in {1, 8} counters, each on its own 128-byte line.  With 8 shards, shard s is the s-th vertical strip
-// of tile columns and the home of the workgroups with blockIdx % 8 == s -- the workgroups one XCD runs -- so an
-// XCD's L2 (4 MiB, not shared with the others) serves one strip's part of the scene; a wave whose home shard has
-// run dry takes tickets from the next shards (every wave fails exactly once on every counter before it leaves).
-// The last wave to leave zeroes the counters for the next launch on the stream.
+// (MI355X_MICROARCH.md, "dequeue"), which a 4000x4000 frame's 250 000 tiles reach, and 4096 waves drawing their first
+// ticket keep it busy for ~46 us of a 0.4 ms frame.  So (a) a wave's FIRST ticket is its own number -- no atomic --
+// and (b) the queue has nshards in {1, 8} counters, each on its own 128-byte line; counter s is the home of the
+// workgroups with blockIdx % 8 == s (the workgroups one XCD runs).  Two layouts:
+//   * the counters TAKE TURNS over one queue (interleave, the default): counter s hands out tickets s, s + 8, ... of
+//     the one adaptive order over all tiles -- the deepest tiles stay first, spread over all XCDs;
+//   * STRIPS: counter s owns the s-th vertical strip of tile columns with its own segment of the order table, so an
+//     XCD's L2 (4 MiB, not shared with the others) serves one strip's part of the scene.
+// A wave whose home counter has run dry takes tickets from the next ones (every wave fails at most once on every
+// counter before it leaves); the last wave to leave zeroes the counters for the next launch on the stream.
 constexpr int kQueueStride = 32;                                // dwords between the shards' counters
 constexpr int kMaxShards = 8;
 constexpr int kQueueExit = kQueueStride * kMaxShards;           // dword index of the counter of waves that have left
@@ -166,7 +170,7 @@ struct KParams {
   unsigned *queue;       // [kQueueDwords] ticket counter of shard s at [kQueueStride * s], waves that have left at [kQueueExit]; all zero between launches
   int nshards;           // 1, or 8 (pooled family, one frame per launch): one ticket counter per XCD ...
   int interleave;        // ... 0: and one strip of tile columns per counter; 1: the counters take turns over ONE queue (order table of a single shard)
-  int static_first;      // pooled family: a wave's first ticket is its own number within its home shard (no atomic: no ramp at launch)
+  int static_first;      // pooled family: a wave's first ticket is its own number among its home counter's waves (no atomic: no ramp at launch)
   int nchunks;           // 8x8 tiles in this part
   int lds_nodes;         // breadth-first node prefix staged in LDS
   int lds_sph;           // sphere prefix staged in LDS

@@ -31,6 +31,15 @@ for i in 0 1 3 4; do
   timeout 300 rocprofv3 --pmc ${PASSES[$i]} --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s $s -n 1000 -m 1000 -r 0 -B 20 > $d.log 2>&1
 done
 done
+# the 10^6-sphere frame (configs[4]): L2 hit rate and memory-side traffic -- the one workload whose scene exceeds the L2s
+if [ -z "$PMC_NO_BIG" ]; then
+  i=0
+  for pass in "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE FETCH_SIZE SQ_INSTS_VMEM" "GRBM_COUNT WRITE_SIZE SQ_INSTS_VALU"; do
+    d=$OUT/big2000_p$i
+    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s big -n 2000 -m 2000 -r 3 > $d.log 2>&1
+    i=$((i+1))
+  done
+fi
 cd $OLDPWD
 python - "$OUT" <<'PY'
 import csv, glob, os, sys, collections

@@ -31,6 +31,8 @@ def main():
     doc = {"_comment": __doc__.split("\n\n")[2].replace("\n", " "),
            "source_sha256": bench.kernel_source_hash(), "sources": bench.KERNEL_SOURCES, "launches": {}}
     for run, c in sorted(runs.items()):
+        if run.startswith("big"):      # the 10^6-sphere frame's passes stay in pmc_summary.csv (DESIGN.md quotes them)
+            continue
         if "_batch" in run:
             # a batch launch of N frames: per-FRAME figures (the launch's counters / N)
             scene, nb = run.rsplit("_batch", 1)
