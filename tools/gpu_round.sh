@@ -32,12 +32,16 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.jso
 export GPU_MAX_HW_QUEUES=20
 for s in rgbbox irreg; do for v in 1 2 3; do echo "== $s 1000x1000 variant $v"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 -v $v $([ $v = 3 ] && echo "-L 24 -o grid_div=4 -o deep_class=0") 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic|Overlapped|Batch"; done; done
 for s in rgbbox irreg; do echo "== $s 1000x1000 variant 3, batch entry (rt_render_batch), library defaults"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 0 -B 20 2>&1 | grep -E "Batch"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 0 -B 200 2>&1 | grep -E "Batch"; done
-for s in rgbbox irreg; do echo "== $s 1000x1000 variant 3, library defaults, one frame at a time"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 2>&1 | grep -E "BVH|Rendering|HIP-event|Throughput"; done
-echo "== irreg 4000x4000 variant 3"; timeout 120 ./build/rtbench -s irreg -n 4000 -m 4000 -r 5 -v 3 2>&1 | grep -E "HIP-event|Throughput|Algorithmic"
-echo "== big 2000x2000 variant 3"; timeout 300 ./build/rtbench -s big -n 2000 -m 2000 -r 3 -v 3 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic"
+for s in rgbbox irreg; do echo "== $s 1000x1000 variant 3, library defaults, one frame at a time"; timeout 120 ./build/rtbench -s $s -n 1000 -m 1000 -r 20 2>&1 | grep -E "BVH|Rendering|HIP-event|Throughput|Checksum"; done
+echo "== irreg 4000x4000 variant 3"; timeout 120 ./build/rtbench -s irreg -n 4000 -m 4000 -r 5 -v 3 2>&1 | grep -E "HIP-event|Throughput|Algorithmic|Checksum"
+echo "== big 2000x2000 variant 3"; timeout 300 ./build/rtbench -s big -n 2000 -m 2000 -r 3 -v 3 2>&1 | grep -E "BVH|HIP-event|Throughput|Algorithmic|Checksum"
 echo "== reference harness (futhark/main.c, unmodified) on our library"
 for s in rgbbox irreg; do timeout 120 ./oracle/_ref/futhark_main -s $s -n 1000 -m 1000 2>&1 | grep -E "construction|Rendering"; done
 } > $OUT/rtbench.log 2>&1
+# per-wave timelines of one frame (instrumented launch) and one rank's share of the bench at world size 8
+for a in "rgbbox 1000 1000" "irreg 1000 1000" "irreg 4000 4000" "big 2000 2000"; do timeout 100 python tools/trace_waves.py $a; done > $OUT/wave_traces.txt 2>&1
+timeout 200 python tools/rank_share_probe.py 20 1,2,4,8 1 0 2s > $OUT/rank_share_probe.txt 2>&1
+timeout 200 python tools/rank_share_probe.py 20 1,8 1 2 2s >> $OUT/rank_share_probe.txt 2>&1
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-serial-extra > $OUT/rocprof_bench.log 2>&1
 cd $OLDPWD
