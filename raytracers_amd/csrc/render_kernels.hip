@@ -527,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               // (64 >> deep_split consecutive pixels: whole rows).  The wave's very first ticket costs no atomic.
               TicketSpan sp;
               const QueueConst qc = queue_const();
-              const unsigned wave_rank = (unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2);
+              const unsigned wave_rank = (unsigned)uni((int)((unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2)));   // (uni: `wave` comes from threadIdx)
               const bool got = queue_draw(q_state, qc, wave_rank, [&](int shard) {
                 unsigned v = 0;
                 if (lane == 0) v = atomicAdd(&p.queue[kQueueStride * shard], 1u);
