@@ -252,6 +252,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.rows_per_tile = rows_per_tile; p.part = part; p.nparts = nparts;
   p.rpt_log2 = (rows_per_tile & (rows_per_tile - 1)) == 0 ? __builtin_ctz(rows_per_tile) : -1;
   p.tiles_x = (p.w + 7) / 8;
+  p.tiles_y = (p.rows_local + 7) / 8;
   p.max_depth = max_depth;
   p.out = out_dev;
   p.stats = ctx->stats_dev;
@@ -876,6 +877,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
   p.rows_local = p.h; p.rows_per_tile = 8; p.part = 0; p.nparts = 1; p.rpt_log2 = 3;
   p.tiles_x = (p.w + 7) / 8;
+  p.tiles_y = (p.rows_local + 7) / 8;
   p.max_depth = max_depth;
   p.out = tmp;
   p.nframes = 1;

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   const int ns_log2 = p.nshards > 1 ? 3 : 0;
   auto queue_const = [&]() {   // (built where it is used: nothing of it stays live across the render loop)
     QueueConst qc;
-    qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.nchunks / p.tiles_x; qc.nframes = p.nframes;
+    qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.tiles_y; qc.nframes = p.nframes;
     qc.interleave = p.interleave;
     qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.ntiles = p.nchunks;
     qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           int slot = -1;
           unsigned long long m = bal(want);
           while (m != 0ull) {            // wave-uniform loop
-            if (q_next == q_end) {
+            if (__builtin_expect(q_next == q_end, 0)) {   // (cold: the register allocator must not favour the draw's values over the hot loop's)
               if (hold) break;           // a deep tile is in flight: no further tickets for now
               // A ticket: 1 << tpt_log2 consecutive positions of a shard's segment (a batch launch and a large frame draw
               // four tiles at a time: 4096 waves on one counter otherwise saturate it -- ~90 atomics per microsecond --
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               q_end = sp.q_end;
               q_enter = true;
             }
-            if (q_enter || (q_next & 63u) == 0u) {
+            if (__builtin_expect(q_enter || (q_next & 63u) == 0u, 0)) {
               q_enter = false;
               // entering a tile: where it is.  A batch launch hands out the tiles of frame 0, then of frame 1, ...:
               // frame f's pixels go to out + f * frame_stride and (when the batch carries cameras) through cams[f]
@@ -566,10 +566,17 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 q_frame_off = (int)(f * (unsigned)p.frame_stride);
                 if (p.cams != nullptr) q_cam = p.cams[f];
               }
-              const QueueConst qc = queue_const();
-              const Shard q_s = shard_of(queue_geo_shard(qc, q_state), queue_geo_log2(qc), qc.tiles_x, qc.tiles_y);   // the shard the ticket came from
-              q_tile = p.order != nullptr ? p.order[t] : shard_tile(q_s, (int)t - q_s.seg, p.tiles_x);   // uniform (scalar) load
-              if (deep_on && (int)t - q_s.seg < queue_ndeep(qc, queue_geo_shard(qc, q_state))) {
+              bool deep_tile;
+              if (p.nshards == 1 || p.interleave) {   // one queue over all tiles: a position is a ticket of the one order
+                q_tile = p.order != nullptr ? p.order[t] : (int)t;   // uniform (scalar) load
+                deep_tile = deep_on && (int)t < p.order[p.nchunks + p.deep_class];
+              } else {                                // strips: the position lies in the segment of the shard the ticket came from
+                const QueueConst qc = queue_const();
+                const Shard q_s = shard_of(queue_shard(q_state), ns_log2, qc.tiles_x, qc.tiles_y);
+                q_tile = p.order != nullptr ? p.order[t] : shard_tile(q_s, (int)t - q_s.seg, p.tiles_x);
+                deep_tile = deep_on && (int)t - q_s.seg < queue_ndeep(qc, queue_shard(q_state));
+              }
+              if (deep_tile) {
                 hold = true;
                 __builtin_amdgcn_s_setprio(3);
               }

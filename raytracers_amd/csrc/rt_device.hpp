@@ -158,6 +158,7 @@ struct KParams {
   int rows_per_tile, part, nparts;
   int rpt_log2;          // log2(rows_per_tile) when it is a power of two, else -1
   int tiles_x;           // ceil(w / 8)
+  int tiles_y;           // ceil(rows_local / 8) (nchunks = tiles_x * tiles_y; on the host: no integer division in the kernel)
   int max_depth;
   int32_t *out;          // [rows_local * w]  (batch launch: frame f at out + f * frame_stride)
   int nframes;           // pooled family: frames rendered by this one launch (>= 1)
