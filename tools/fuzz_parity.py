@@ -58,7 +58,11 @@ while time.time() < t_end:
                  deep_class=int(rng.integers(0, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
                  lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])),
                  wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])),
-                 deep_split=int(rng.integers(0, 4)))
+                 deep_split=int(rng.integers(0, 4)),
+                 # the tile queue: one counter / a strip of tile columns per counter / counters taking turns, tiles per ticket,
+                 # the waves' first tickets without an atomic
+                 xcd_queues=int(rng.choice([-1, 0, 1, 2])), tpt_log2=int(rng.choice([-1, -1, 0, 1, 2, 3, 4])),
+                 static_first=int(rng.choice([0, 1, 1])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):
@@ -76,6 +80,16 @@ while time.time() < t_end:
             ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
             if variant == 3:                            # third frame: the ticket counter after a frame with deep-tile pieces
                 ok &= int((R.render(h, w, ps, max_depth=md) != ref).sum()) == 0
+    # a batch of three frames in one launch (class-major tickets over the frames), after the view's order has settled
+    ctx.set_variant(3)
+    if h * w * 3 < (1 << 28):
+        import torch
+        nb = 3
+        batch = torch.full((nb, h, w), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(batch.data_ptr(), h, w, ps, nb, frame_stride=h * w, max_depth=md)
+        ctx.sync()
+        ok &= all(int((f != ref).sum()) == 0 for f in batch.cpu().numpy())
     # the row-tile partition: every part rendered on its own, assembled in one launch
     ctx.set_option("gpu_build", 1)
     ctx.set_variant(0)
