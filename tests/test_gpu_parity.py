@@ -449,6 +449,32 @@ def test_tile_queue_layouts_render_every_pixel(R, scene, h, w, xcd, tpt, static_
     c.close()
 
 
+@pytest.mark.parametrize("scene,h,w", [("rgbbox", 200, 200), ("irreg", 333, 250)])
+def test_wave_trace_of_the_instrumented_launch(R, scene, h, w):
+    """rt_render_trace (what tools/trace_waves.py reads): the instrumented pooled launch in the production workgroup shape
+    writes one record per wave; the leaf items all waves processed are exactly the oracle's sphere tests, every wave
+    started, ended and left the tile queue, and the launch leaves the ticket counters zeroed (the frame after it is right)."""
+    import ctypes as C
+    from raytracers_amd._lib import lib
+    c = R.Context()
+    c.set_variant(3)
+    ps = R.prepare_scene(h, w, c.scene(scene))
+    want, cnt = _oracle(scene).render(h, w)
+    for _ in range(2):   # recording frame, ordered frame
+        assert int((R.render(h, w, ps) != want).sum()) == 0
+    rec = np.zeros((8192, 8), dtype=np.uint64)
+    n = C.c_int32()
+    c._check(lib.rt_render_trace(c._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
+    assert 0 < n.value <= 8192
+    rec = rec[: n.value].astype(np.int64)
+    assert (rec[:, 0] > 0).all() and (rec[:, 2] >= rec[:, 0]).all()            # start / end wall clock
+    assert int((rec[:, 6] & 0xFFFFFFFF).sum()) == cnt["leaf_tests"]              # leaf items == sphere tests
+    ops = (rec[:, 3] & 0x1FFFFF) + ((rec[:, 3] >> 21) & 0x1FFFFF) + ((rec[:, 3] >> 42) & 0x1FFFFF)
+    assert int(ops.sum()) > 0 and int((rec[:, 7] & 0xFFFF).max()) >= 1          # operations ran, a bounce chain was seen
+    assert int((R.render(h, w, ps) != want).sum()) == 0
+    c.close()
+
+
 # ---------------------------------------------------------------- row-tile partition ------
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("nparts", [2, 3, 8])
