@@ -404,6 +404,9 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (hipMemset(ctx->queue_dev, 0, sizeof(unsigned) * rtk::kQueueDwords) != hipSuccess) return bail(7);
   if (hipMalloc(reinterpret_cast<void **>(&ctx->stats_dev), 256) != hipSuccess) return bail(7);
   if (hipMemset(ctx->stats_dev, 0, 256) != hipSuccess) return bail(7);
+  // the memsets run on the null stream, the context's own stream does not wait for it: the counters must BE zero
+  // before the first launch draws a ticket
+  if (hipStreamSynchronize(nullptr) != hipSuccess) return bail(7);
   if (hipMalloc(reinterpret_cast<void **>(&ctx->arena), kArenaGranules * kGranule) != hipSuccess) return bail(7);
   ctx->arena_used.assign(kArenaGranules, 0);
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault) != hipSuccess)
