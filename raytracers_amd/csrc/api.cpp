@@ -294,7 +294,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.queue = ctx->queue_dev;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
   // tiles per ticket: one ticket counter saturates at ~88 draws per microsecond, which batches and large frames reach
-  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (nframes > 1 ? 2 : 0);
+  // (a batch: four tiles per ticket while every wave still gets a few dozen tiles -- the bench's 20 frames of 1000x1000 are 76
+  // tiles per wave -- fewer when a launch is small: a rank's eighth of those frames is 10-20 tiles per wave, and with four per
+  // ticket the waves' loads differ by whole tickets)
+  const int64_t tiles_per_wave = static_cast<int64_t>(p.nchunks) * nframes / std::max(1, pl.grid * pl.waves);
+  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (nframes > 1 ? (tiles_per_wave >= 48 ? 2 : tiles_per_wave >= 24 ? 1 : 0) : 0);
   // Eight ticket counters (one per XCD: workgroup b runs on XCD b % 8).  Default: they take turns over ONE queue (counter
   // s hands out tickets s, s + 8, ...): the adaptive order stays global and one word no longer carries every draw --
   // measured against one counter: irreg 1000x1000 -8 %, 4000x4000 -38 %, the 10^6-sphere frame -18 %, rgbbox +-1 %.
