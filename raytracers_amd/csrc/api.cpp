@@ -293,7 +293,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.cams = reinterpret_cast<const rtk::Cam *>(cams_dev);
   p.queue = ctx->queue_dev;
   p.nchunks = p.tiles_x * ((p.rows_local + 7) / 8);
-  // tiles per ticket: one ticket counter saturates at ~88 draws per microsecond, which batches and large frames reach
+  // Tiles per ticket.  A frame: one (with eight counters nothing saturates, and several tiles per ticket cost the 10^6-sphere
+  // frame 37 %: a wave then walks adjacent expensive tiles one after the other).
   // (a batch: four tiles per ticket while every wave still gets a few dozen tiles -- the bench's 20 frames of 1000x1000 are 76
   // tiles per wave -- fewer when a launch is small: a rank's eighth of those frames is 10-20 tiles per wave, and with four per
   // ticket the waves' loads differ by whole tickets)
