@@ -89,6 +89,23 @@ def test_wave_state_machine_matches_oracle(scene, h, w):
     assert "diff_vs_simple 0" in pers
 
 
+def test_bench_checksum_arithmetic_on_the_cpu():
+    """bench.py verifies every timed image with c = c * 31 + pixel evaluated as a wrapping polynomial on the device;
+    the same code on CPU tensors must agree with the sequential definition (oracle_lib.checksum) -- also for pixels
+    with the sign bit set (poison pattern) and for a size that is not a power of two."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    cks = bench.Checksummer(torch.device("cpu"))
+    rng = np.random.default_rng(7)
+    for shape in ((1, 1), (37, 53), (200, 200)):
+        px = rng.integers(-2**31, 2**31 - 1, size=shape, dtype=np.int64).astype(np.int32)
+        assert cks(torch.from_numpy(px)) == O.checksum(px)
+    px, _ = O.OracleScene("rgbbox").render(200, 200)
+    assert "%08x" % cks(torch.from_numpy(px)) == "9082f119" == "%08x" % O.checksum(px)   # SURVEY.md 8c's rgbbox 200x200
+
+
 def test_tile_queue_protocol_on_the_cpu():
     """tools/queue_check drives the pooled kernel's ticket arithmetic (the __host__ __device__ functions of
     rt_device.hpp: shards = strips of tile columns, deep-tile pieces, multi-tile tickets, static first tickets,
