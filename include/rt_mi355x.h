@@ -135,10 +135,11 @@ int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_p
 int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                     uint64_t stats3[3]);
 
-/* Diagnostic: one instrumented launch of the pooled kernel; per wave 8 x u64 = {wall clock (100 MHz ticks,
+/* Diagnostic: one instrumented launch of the pooled kernel; per wave 16 x u64 = {wall clock (100 MHz ticks,
  * chip-wide) at start, at queue exhaustion, at exit; #BOX | #LEAF << 21 | #SHADE << 42 operations; shader
- * cycles lived; 0; (box items << 32 | leaf items); deepest bounce chain finished | max box stack << 16 |
- * max leaf list << 32}. */
+ * cycles lived; #BOXT | #BOX2 << 32 (both are counted in #BOX as well); (box items << 32 | leaf items); deepest bounce
+ * chain finished | max box stack << 16 | max leaf list << 32; shader cycles spent inside BOX, BOX2, BOXT, LEAF, SHADE
+ * operations (words 8..12); 13..15 reserved}. */
 int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                     uint64_t *records, int32_t max_waves, int32_t *num_waves);
 

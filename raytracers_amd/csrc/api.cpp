@@ -318,6 +318,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
+  p.tl_log2 = ps->tl_depth;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -355,6 +356,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.order = to->valid ? to->order : nullptr;
       p.deep_class = ctx->deep_class;
       p.deep_split = ctx->deep_split;
+      p.deep_cap_log2 = ctx->deep_cap_log2;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
@@ -522,13 +524,22 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->adaptive_order = v;
   } else if (k == "box2") {
     ctx->box2 = v != 0;
+  } else if (k == "treelet") {
+    if (v < 1 || v > rtk::kTreeletMaxDepth) return fail(ctx, "treelet must be 1 (no treelets) .. 5 levels per treelet");
+    ctx->treelet = v;
+  } else if (k == "trace_part") {
+    ctx->trace_part = v;
+  } else if (k == "trace_nparts") {
+    ctx->trace_nparts = v;
   } else if (k == "ray_planes") {
     if (v != 0 && v != 2 && v != 3) return fail(ctx, "ray_planes must be 0 (auto), 2 or 3");
     ctx->ray_planes = v;
   } else if (k == "deep_class") {
     ctx->deep_class = std::min(8, std::max(0, v));
+  } else if (k == "deep_cap_log2") {
+    ctx->deep_cap_log2 = std::min(8, std::max(0, v));
   } else if (k == "deep_split") {
-    ctx->deep_split = std::min(3, std::max(0, v));
+    ctx->deep_split = std::min(6, std::max(0, v));
   } else if (k == "xcd_queues") {
     if (v < -1 || v > 2) return fail(ctx, "xcd_queues must be -1 (auto), 0 (one counter), 1 (a strip of tile columns per counter) or 2 (counters take turns)");
     ctx->xcd_queues = v;
@@ -667,8 +678,9 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     }
   } else {
     const rt::Lbvh bvh = rt::build_lbvh(scene->desc.spheres);
-    const rt::TravLayout tl = rt::make_trav_layout(bvh);
+    const rt::TravLayout tl = rt::make_trav_layout(bvh, ctx->treelet);
     ps->height = tl.height;
+    ps->tl_depth = tl.treelet_depth;
     put(ps->L7, bvh.L.data(), n * sizeof(rt::Sphere));
     put(ps->bmin, bvh.bmin.data(), ni * 3 * sizeof(float));
     put(ps->bmax, bvh.bmax.data(), ni * 3 * sizeof(float));
@@ -867,11 +879,11 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   int32_t *tmp = nullptr;
   unsigned long long *trace = nullptr;
   RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(int32_t) * static_cast<size_t>(h) * w));
-  if (hipError_t em = hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * 8 * static_cast<size_t>(nw)); em != hipSuccess) {
+  if (hipError_t em = hipMalloc(reinterpret_cast<void **>(&trace), sizeof(unsigned long long) * rtk::kTraceWords * static_cast<size_t>(nw)); em != hipSuccess) {
     (void)hipFree(tmp);
     return hip_fail(ctx, em, "hipMalloc(trace)");
   }
-  if (hipError_t em = hipMemsetAsync(trace, 0, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), ctx->stream); em != hipSuccess) {
+  if (hipError_t em = hipMemsetAsync(trace, 0, sizeof(unsigned long long) * rtk::kTraceWords * static_cast<size_t>(nw), ctx->stream); em != hipSuccess) {
     (void)hipFree(tmp);
     (void)hipFree(trace);
     return hip_fail(ctx, em, "hipMemsetAsync(trace)");
@@ -883,7 +895,10 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.n_nodes = static_cast<int>(ps->n - 1); p.n_sph = static_cast<int>(ps->n);
   std::memcpy(&p.cam, &ps->cam, sizeof(p.cam));
   p.w = static_cast<int>(w); p.h = static_cast<int>(h);
-  p.rows_local = p.h; p.rows_per_tile = 8; p.part = 0; p.nparts = 1; p.rpt_log2 = 3;
+  // (diagnostic knobs trace_part / trace_nparts: the timeline of one part of the cyclic row-tile partition -- a band alone on the chip)
+  p.rows_per_tile = 8; p.part = ctx->trace_part; p.nparts = std::max(1, ctx->trace_nparts); p.rpt_log2 = 3;
+  if (p.part < 0 || p.part >= p.nparts) p.part = 0;
+  p.rows_local = static_cast<int>(rt::part_rows(h, 8, p.part, p.nparts));
   p.tiles_x = (p.w + 7) / 8;
   p.tiles_y = (p.rows_local + 7) / 8;
   p.max_depth = max_depth;
@@ -904,20 +919,22 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
+  p.tl_log2 = ps->tl_depth;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {
     // use the adaptive order of the matching view if one exists (read-only here)
     for (auto &o : ps->orders)
-      if (o.h == h && o.w == w && o.part == 0 && o.nparts == 1 && o.max_depth == max_depth && o.valid &&
+      if (o.h == h && o.w == w && o.part == p.part && o.nparts == p.nparts && o.max_depth == max_depth && o.valid &&
           ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
         p.order = o.order;
         p.deep_class = ctx->deep_class;
         p.deep_split = ctx->deep_split;
+        p.deep_cap_log2 = ctx->deep_cap_log2;
       }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * 8 * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * rtk::kTraceWords * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
   }
   (void)hipFree(tmp);
   (void)hipFree(trace);

@@ -253,31 +253,64 @@ Lbvh build_lbvh(const std::vector<Sphere> &ts) {
   return out;
 }
 
-TravLayout make_trav_layout(const Lbvh &b) {
+TravLayout make_trav_layout(const Lbvh &b, int treelet_depth) {
   TravLayout t;
   const int64_t n = b.n;
   if (n < 2) return t;
   const size_t ni = static_cast<size_t>(n - 1);
-  // breadth-first numbering from the root (canonical node 0)
-  std::vector<int32_t> bfs;          // traversal index -> canonical index
-  std::vector<int32_t> level_of;     // per traversal index
-  bfs.reserve(ni);
-  level_of.reserve(ni);
-  t.bfs_of_canon.assign(ni, -1);
-  bfs.push_back(0);
-  level_of.push_back(0);
-  t.bfs_of_canon[0] = 0;
+  const int D = std::min(std::max(treelet_depth, 1), rtk::kTreeletMaxDepth);
+  t.treelet_depth = D;
+  // depth of every inner node (canonical node 0 is the root), and on which side of its parent it hangs
+  std::vector<int32_t> depth(ni, 0);
+  std::vector<uint8_t> is_right(ni, 0);
   int height = 1;
-  for (size_t head = 0; head < bfs.size(); ++head) {
-    const int32_t c = bfs[head];
-    const int32_t kids[2] = {b.left[c], b.right[c]};
-    height = std::max(height, level_of[head] + 1);
-    for (int32_t k : kids) {
-      if (ptr_is_leaf(k)) continue;
-      t.bfs_of_canon[k] = static_cast<int32_t>(bfs.size());
-      bfs.push_back(k);
-      level_of.push_back(level_of[head] + 1);
+  {
+    std::vector<int32_t> todo{0};
+    for (size_t head = 0; head < todo.size(); ++head) {
+      const int32_t c = todo[head];
+      height = std::max(height, depth[c] + 1);
+      const int32_t kids[2] = {b.left[c], b.right[c]};
+      for (int k = 0; k < 2; ++k) {
+        if (ptr_is_leaf(kids[k])) continue;
+        depth[kids[k]] = depth[c] + 1;
+        is_right[kids[k]] = static_cast<uint8_t>(k);
+        todo.push_back(kids[k]);
+      }
     }
+  }
+  // Treelet-major numbering (treelet.h): treelets in (depth of the root, canonical index of the root) order, the nodes
+  // of a treelet by heap index.  D == 1: every node is its own treelet = numbering by (depth, canonical index).
+  std::vector<int32_t> root_of(ni), heap_of(ni);
+  std::vector<uint32_t> occ(ni, 0u);
+  for (size_t c = 0; c < ni; ++c) {
+    int32_t a = static_cast<int32_t>(c), path = 0;
+    const int rel = depth[c] % D;
+    for (int s = 0; s < rel; ++s) {   // path bits, the step nearest the root ends up most significant
+      path |= static_cast<int32_t>(is_right[a]) << s;
+      a = b.parent[a];
+    }
+    root_of[c] = a;
+    heap_of[c] = (1 << rel) - 1 + path;
+    occ[static_cast<size_t>(a)] |= 1u << heap_of[c];
+  }
+  std::vector<int32_t> by_depth(ni);
+  for (size_t c = 0; c < ni; ++c) by_depth[c] = static_cast<int32_t>(c);
+  std::stable_sort(by_depth.begin(), by_depth.end(), [&](int32_t x, int32_t y) { return depth[x] < depth[y]; });
+  std::vector<int32_t> base(ni, 0);
+  {
+    int32_t run = 0;
+    for (int32_t c : by_depth)
+      if (depth[c] % D == 0) {
+        base[c] = run;
+        run += rtk::tl_popc(occ[c]);
+      }
+  }
+  std::vector<int32_t> bfs(ni);      // traversal index -> canonical index
+  t.bfs_of_canon.assign(ni, -1);
+  for (size_t c = 0; c < ni; ++c) {
+    const int32_t ti = base[root_of[c]] + rtk::tl_pos(occ[root_of[c]], heap_of[c]);
+    t.bfs_of_canon[c] = ti;
+    bfs[static_cast<size_t>(ti)] = static_cast<int32_t>(c);
   }
   t.height = height;
   t.nodes.resize(ni);
@@ -309,6 +342,10 @@ TravLayout make_trav_layout(const Lbvh &b) {
     const int32_t l8 = static_cast<int32_t>(static_cast<uint32_t>(nd.left) << 8), r8 = static_cast<int32_t>(static_cast<uint32_t>(nd.right) << 8);
     std::memcpy(&q[3], &l8, 4);
     std::memcpy(&q[7], &r8, 4);
+    const int32_t c = bfs[ti];
+    const rtk::TlMasks m = rtk::tl_masks(occ[root_of[c]], heap_of[c], D);
+    std::memcpy(&q[11], &m.l, 4);
+    std::memcpy(&q[15], &m.r, 4);
   }
   for (int a = 0; a < 3; ++a) {
     t.root_lo[a] = t.nodes[0].lo[a];

@@ -24,6 +24,7 @@
 
 #include "lane_core.h"
 #include "rt_device.hpp"
+#include "treelet.h"
 
 namespace rtk {
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     QueueConst qc;
     qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.tiles_y; qc.nframes = p.nframes;
     qc.interleave = p.interleave;
-    qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.ntiles = p.nchunks;
+    qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.cap_log2 = p.deep_cap_log2; qc.ntiles = p.nchunks;
     qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
     qc.home_waves = nwaves >> ns_log2;                       // the same for every shard (the grid is a multiple of nshards)
     qc.q_static = p.static_first ? qc.home_waves : 0u;
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   bool q_enter = false;    // a ticket was drawn: (re)derive the tile's position
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
+  unsigned long long tr_cyc[5] = {0, 0, 0, 0, 0}, tr_nt = 0, tr_nb2 = 0;   // shader cycles inside BOX / BOX2 / BOXT / LEAF / SHADE operations, treelet operations
   int tr_maxdepth = 0, tr_maxbox = 0, tr_maxleaf = 0;
   if (STATS) {
     tr_t0 = wall_clock64();   // 100 MHz, one counter for the whole chip (clock64 is per XCD)
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
           bool root = false;
           if (STATS) tr_ops[2]++;
+          const unsigned long long tr_s0 = STATS ? clock64() : 0ull;
           if (done) {
             if (STATS) tr_maxdepth = depth > tr_maxdepth ? depth : tr_maxdepth;
             const unsigned long long key = wkey[lane];
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             else if (bal(live && depth >= p.prio_depth) != 0ull) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
           }
+          if (STATS) tr_cyc[4] += clock64() - tr_s0;
           continue;
         }
       }
@@ -642,6 +646,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     if (leaf_op) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
+      const unsigned long long tr_l0 = STATS ? clock64() : 0ull;
       const int top = nleaf - 1 - lane;
       const unsigned item = wleaf[top < 0 ? 0 : top];
       const bool act = top >= 0;
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       if (act & (g < kTMax))
         atomicMin(&wkey[sl],
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
+      if (STATS) { __builtin_amdgcn_s_waitcnt(0); tr_cyc[3] += clock64() - tr_l0; }
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
       // (two instantiations: a FULL batch -- every lane has an item: no clamp, no activity mask -- and the general one)
@@ -809,9 +815,18 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int d = sel_mask(m_inl, 0, 1) + sel_mask(m_inr, 0, 1) - sel_mask(bal(act & (role == 0)), 0, 1);
         lds_add_masked(bal(d != 0), (int)(size_t)wcnt + sl4, d);
       };
+      const unsigned long long tr_b0 = STATS ? clock64() : 0ull;
+      int tr_kind = 0;
       if (nbox >= 64) box(std::true_type{});
-      else if (nbox <= 32 && p.box2) box2();
+      else if (nbox <= 32 && p.box2) { box2(); tr_kind = 1; }
       else box(std::false_type{});
+      if (STATS) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long dt = clock64() - tr_b0;
+        if (tr_kind == 0) tr_cyc[0] += dt;
+        else if (tr_kind == 1) { tr_cyc[1] += dt; tr_nb2++; }
+        else tr_cyc[2] += dt;
+      }
     }
   }
   queue_leave(p, nwaves, lane);
@@ -824,11 +839,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       int md = tr_maxdepth;
       for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(md, o); md = other > md ? other : md; }
       if (lane == 0) {
-        unsigned long long *rec = p.trace + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 8;
+        unsigned long long *rec = p.trace + (size_t)(blockIdx.x * (THREADS / 64) + wave) * kTraceWords;
         rec[0] = tr_t0; rec[1] = tr_exh; rec[2] = t_end;
         rec[3] = tr_ops[0] | (tr_ops[1] << 21) | (tr_ops[2] << 42);
         rec[4] = c_end - tr_c0;   // shader cycles of this wave's life
-        rec[5] = 0;
+        rec[5] = tr_nt | (tr_nb2 << 32);
+        rec[8] = tr_cyc[0]; rec[9] = tr_cyc[1]; rec[10] = tr_cyc[2]; rec[11] = tr_cyc[3]; rec[12] = tr_cyc[4];
         rec[6] = (tr_items[0] << 32) | tr_items[1];
         rec[7] = (unsigned long long)md | ((unsigned long long)tr_maxbox << 16) | ((unsigned long long)tr_maxleaf << 32);
       }

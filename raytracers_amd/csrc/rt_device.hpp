@@ -7,6 +7,7 @@
 
 namespace rtk {
 
+constexpr int kTraceWords = 16;   // u64 per wave of the instrumented pooled launch's timeline (rt_render_trace)
 constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>= any LBVH height)
 // pooled_kernel: a wave's LDS region in dwords: hit keys 64 x u64, counters 64, dump 4, then the ray
 // table (ray_planes x 64 float4), the box stack and the leaf list
@@ -85,6 +86,7 @@ struct QueueConst {
   int ns_log2, tiles_x, tiles_y, nframes;
   int interleave;            // 1: the shards are not strips but every (1 << ns_log2)-th ticket of ONE queue over all tiles (geometry and tables of a single shard)
   int ds, tpt;               // deep_split, tpt_log2
+  int cap_log2;              // the pieces of split tiles may occupy one in 2^cap_log2 of the waves
   int ntiles;                // all shards' tiles: the class tables sit at order[ntiles + kOrderTableDw * shard]
   const int *order;          // nullptr: no tables
   int deep_class;            // 0: no deep tiles
@@ -105,6 +107,12 @@ __host__ __device__ inline int queue_geo_log2(const QueueConst &c) { return c.in
 __host__ __device__ inline int queue_ndeep(const QueueConst &c, int shard) {
   return (c.order != nullptr && c.deep_class > 0) ? c.order[c.ntiles + kOrderTableDw * shard + c.deep_class] : 0;
 }
+// deep tiles handed out in pieces: the deepest ones, as many as one in 2^cap_log2 of the waves the queue (strips: the
+// shard) serves can take
+__host__ __device__ inline unsigned queue_nsplit(const QueueConst &c, int ndeep) {
+  const int cap = (int)((c.interleave ? c.home_waves << c.ns_log2 : c.home_waves) >> (c.cap_log2 + c.ds));
+  return c.ds > 0 ? (unsigned)(ndeep < cap ? ndeep : cap) : 0u;
+}
 template <class FetchAdd>
 __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c, unsigned wave_rank, FetchAdd &&fetch_add, TicketSpan *sp) {
   const unsigned all = ((1u << (1 << c.ns_log2)) - 1u) << 8;
@@ -114,9 +122,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
     const Shard s = shard_of(geo, queue_geo_log2(c), c.tiles_x, c.tiles_y);
     const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
     const int ndeep = queue_ndeep(c, geo);               // (<= the shard's tiles: a position of its class table)
-    // the pieces may occupy a 32nd of the waves the queue (strips: the shard) serves
-    const int cap = (int)((c.interleave ? c.home_waves << c.ns_log2 : c.home_waves) >> (5 + c.ds));
-    const unsigned n_split = c.ds > 0 ? (unsigned)(ndeep < cap ? ndeep : cap) : 0u;
+    const unsigned n_split = queue_nsplit(c, ndeep);
     unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
     // interleaved: this counter's tickets are the queue's tickets sh, sh + n, sh + 2 n, ... (n counters)
     if (c.interleave) tickets = (tickets + (1u << c.ns_log2) - 1u - (unsigned)sh) >> c.ns_log2;
@@ -146,7 +152,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
 struct KParams {
   // scene (traversal copy; see rt::TravLayout)
   const float4 *nodes;   // [2*(n-1)]  {lo.xyz, left}, {hi.xyz, right}; child >= 0 inner, < 0 ~leaf
-  const float4 *nodes64; // [4*(n-1)]  pooled family: {L.lo,left<<8} {L.hi,right<<8} {R.lo,0} {R.hi,0} (children's boxes)
+  const float4 *nodes64; // [4*(n-1)]  pooled family: {L.lo,left<<8} {L.hi,right<<8} {R.lo,mask_l} {R.hi,mask_r} (children's boxes; treelet masks)
   const float4 *sph;     // [n] {pos.xyz, radius}
   const float4 *col;     // [n] {colour.rgb, 1/radius}
   float root_lo[3], root_hi[3];   // the root's own box
@@ -166,7 +172,7 @@ struct KParams {
   int frame_stride;      // int32 elements between consecutive frames' buffers
   const Cam *cams;       // [nframes] per-frame cameras (nullptr: `cam` for every frame)
   unsigned long long *stats;   // [3] rays, box tests, sphere tests (instrumented launches only)
-  unsigned long long *trace;   // [waves][8] per-wave timeline (instrumented pooled launch only)
+  unsigned long long *trace;   // [waves][kTraceWords] per-wave timeline (instrumented pooled launch only)
   // persistent family
   unsigned *queue;       // [kQueueDwords] ticket counter of shard s at [kQueueStride * s], waves that have left at [kQueueExit]; all zero between launches
   int nshards;           // 1, or 8 (pooled family, one frame per launch): one ticket counter per XCD ...
@@ -183,8 +189,10 @@ struct KParams {
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
+  int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)
   int deep_class;        // a shard's positions below its class table's entry [deep_class] are "deep" tiles (0: feature off)
   int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)
+  int deep_cap_log2;     // ... to at most one in 2^this of the launch's waves (5)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row

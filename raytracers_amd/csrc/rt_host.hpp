@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include "treelet.h"
+
 namespace rt {
 
 // sphere = {pos, colour, radius} (ray.fut:22-24); 7 packed floats.
@@ -58,8 +60,8 @@ Camera scene_camera(const SceneDesc &sc, int64_t h, int64_t w);
 Lbvh build_lbvh(const std::vector<Sphere> &ts);   // bvh_mk sphere_aabb (bvh.fut:30-59)
 
 // ---- traversal copy consumed by the kernels ----
-// One 32-byte record per inner node, renumbered breadth-first so that the nodes
-// nearest the root form a prefix (the part staged in LDS).  Child references:
+// One 32-byte record per inner node, renumbered treelet by treelet (treelet.h; treelets in order of their
+// roots' depth, so the nodes nearest the root form a prefix: the part staged in LDS).  Child references:
 // >= 0 -> inner node (traversal numbering); < 0 -> leaf, sphere index = ~ref
 // (leaf indices are NOT renumbered: the lowest index wins ties, bvh.fut:61-84).
 struct TravNode {
@@ -76,15 +78,16 @@ struct TravLayout {
   std::vector<float> col;            // [n][4] colour.rgb, 1/radius (hit normal's scale, ray.fut:44)
   // 64-byte records for the pooled kernel: a work item is an inner node whose own box already
   // passed, so the record carries what its CHILDREN need: {L.lo.xyz, left << 8} {L.hi.xyz, right << 8}
-  // {R.lo.xyz, 0} {R.hi.xyz, 0}, where L/R are the child's box when the child is an inner node
+  // {R.lo.xyz, mask_l} {R.hi.xyz, mask_r}, where L/R are the child's box when the child is an inner node
   // (unused for a leaf child: the reference keeps no leaf boxes, bvh.fut:84).  The references are stored
   // pre-shifted: a work item of the pooled kernel is (reference << 8) | (slot * 4).
-  std::vector<float> nodes64;        // [n-1][16] breadth-first
+  std::vector<float> nodes64;        // [n-1][16]; mask_l / mask_r: the node's treelet masks (treelet.h)
+  int treelet_depth = 1;             // levels per treelet (1: every node is its own treelet = numbering by depth)
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};   // box of the root (tested when a ray starts)
   std::vector<int32_t> bfs_of_canon; // canonical inner index -> traversal index
   int height = 0;                    // edges on the longest root -> leaf path
 };
-TravLayout make_trav_layout(const Lbvh &b);
+TravLayout make_trav_layout(const Lbvh &b, int treelet_depth = 1);
 
 // rows owned by part p of nparts under the cyclic row-tile partition
 int64_t part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);

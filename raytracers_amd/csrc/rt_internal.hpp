@@ -33,6 +33,8 @@ struct rt_context {
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
+  int treelet = 1;          // prepare_scene cuts the traversal copy into treelets of this many levels (treelet.h; 1: none)
+  int trace_part = 0, trace_nparts = 1;   // rt_render_trace: which part of the row-tile partition the instrumented launch renders
   int ray_planes = 0;       // pooled family: planes of the LDS ray table (0 = chosen with the workgroup shape, 2, 3)
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
@@ -40,6 +42,7 @@ struct rt_context {
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
   int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
   int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
+  int deep_cap_log2 = 5;    // ... while the pieces occupy at most one in 2^this of the launch's waves
   int xcd_queues = -1;      // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp); -1: frames of >= 32768 tiles
   int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers (-1: 2 for batches and frames of >= 32768 tiles, else 0)
   int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
@@ -101,6 +104,7 @@ struct rt_prepared {
   int64_t h = 0, w = 0;
   rt::Camera cam{};
   int height = 0;   // tree height
+  int tl_depth = 1; // levels per treelet of the traversal copy (1: no treelets)
   // canonical {L, I} on the device (SoA, as bvh.fut:28 lays them out)
   float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
   int32_t *left = nullptr, *right = nullptr, *parent = nullptr;

@@ -157,6 +157,49 @@ def test_big_2000_at_size(R, ctx):
     mc.close()
 
 
+@pytest.mark.parametrize("treelet", [1, 2, 3, 4, 5])
+def test_treelet_numbering_does_not_change_pixels(R, treelet):
+    """The traversal copy numbered treelet by treelet (treelet.h) under every cut depth: frames, a part of three, a
+    batch, on the reference scenes, another tree shape and a scene with duplicates."""
+    import torch
+    c = R.Context()
+    c.set_variant(3)
+    c.set_option("treelet", treelet)
+    rng = np.random.default_rng(5)
+    s = np.zeros((700, 7), np.float32)
+    s[:, 0:3] = rng.uniform(-40, 40, (700, 3))
+    s[:, 3:6] = rng.uniform(0.2, 1.0, (700, 3))
+    s[:, 6] = rng.uniform(0.5, 6.0, 700)
+    s[100:160, 0:3] = s[0:60, 0:3]
+    s[200:260] = s[300:360]
+    lf, la, fov = (5.0, 25.0, 70.0), (0.0, 0.0, 0.0), 60.0
+    cases = [("rgbbox", None, 333, 250), ("irreg", None, 200, 280), ("floor:37:222", None, 90, 120),
+             ("custom", O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov), 150, 200)]
+    for gpu_build in (0, 1):
+        c.set_option("gpu_build", gpu_build)
+        for name, orc, h, w in cases:
+            orc = orc or _oracle(name)
+            want, cnt = orc.render(h, w)
+            sc = c.scene_from_spheres(s, lf, la, fov) if name == "custom" else _scene(c, name)
+            ps = R.prepare_scene(h, w, sc)
+            for frame in range(3):   # cold view, ordered view with deep tiles, again
+                got = R.render(h, w, ps)
+                assert int((got != want).sum()) == 0, (name, gpu_build, frame)
+            buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+            c.sync()
+            assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, gpu_build, "batch")
+            part = torch.full((R.part_rows(h, 1, 3), w), -3, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
+            c.sync()
+            from raytracers_amd.dist import tile_rows
+            assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, gpu_build, "part")
+            ps.free()
+    c.close()
+
+
 @pytest.mark.parametrize("variant", [1, 3])
 def test_host_built_scene_renders_identically(R, variant):
     """The two builders number the traversal copy differently (breadth-first vs by depth); pixels
@@ -462,7 +505,7 @@ def test_wave_trace_of_the_instrumented_launch(R, scene, h, w):
     want, cnt = _oracle(scene).render(h, w)
     for _ in range(2):   # recording frame, ordered frame
         assert int((R.render(h, w, ps) != want).sum()) == 0
-    rec = np.zeros((8192, 8), dtype=np.uint64)
+    rec = np.zeros((8192, 16), dtype=np.uint64)
     n = C.c_int32()
     c._check(lib.rt_render_trace(c._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
     assert 0 < n.value <= 8192

@@ -62,7 +62,9 @@ while time.time() < t_end:
                  # the tile queue: one counter / a strip of tile columns per counter / counters taking turns, tiles per ticket,
                  # the waves' first tickets without an atomic
                  xcd_queues=int(rng.choice([-1, 0, 1, 2])), tpt_log2=int(rng.choice([-1, -1, 0, 1, 2, 3, 4])),
-                 static_first=int(rng.choice([0, 1, 1])))
+                 static_first=int(rng.choice([0, 1, 1])),
+                 # the treelet cut of the traversal copy (levels per treelet: the numbering must never matter)
+                 treelet=int(rng.integers(1, 6)))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):

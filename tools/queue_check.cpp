@@ -19,6 +19,7 @@ using namespace rtk;
 
 struct Cfg {
   int tiles_x, tiles_y, ns_log2, nframes, ds, tpt, deep_class, waves, static_first, interleave;
+  int cap_log2 = 5;
 };
 
 static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
@@ -51,7 +52,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
 
   QueueConst qc;
   qc.ns_log2 = c.ns_log2; qc.tiles_x = c.tiles_x; qc.tiles_y = c.tiles_y; qc.nframes = c.nframes;
-  qc.ds = c.ds; qc.tpt = c.tpt; qc.ntiles = ntiles; qc.interleave = c.interleave;
+  qc.ds = c.ds; qc.tpt = c.tpt; qc.cap_log2 = c.cap_log2; qc.ntiles = ntiles; qc.interleave = c.interleave;
   const bool deep_on = c.nframes == 1 && c.deep_class > 0;
   qc.order = deep_on ? order.data() : nullptr; qc.deep_class = c.deep_class;
   qc.home_waves = static_cast<unsigned>(c.waves >> c.ns_log2);
@@ -107,8 +108,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
     const int geo = c.interleave ? 0 : s;
     const Shard sh = shard_of(geo, gl2, c.tiles_x, c.tiles_y);
     const int ndeep = queue_ndeep(qc, geo);
-    const int cap = static_cast<int>((c.interleave ? qc.home_waves << c.ns_log2 : qc.home_waves) >> (5 + c.ds));
-    const unsigned n_split = c.ds > 0 ? static_cast<unsigned>(ndeep < cap ? ndeep : cap) : 0u;
+    const unsigned n_split = queue_nsplit(qc, ndeep);
     unsigned tk = shard_tickets(static_cast<unsigned>(sh.ntiles) * c.nframes, n_split, static_cast<unsigned>(ndeep), c.ds, c.tpt);
     if (c.interleave) tk = (tk + static_cast<unsigned>(ns) - 1u - static_cast<unsigned>(s)) >> c.ns_log2;
     const unsigned dyn = tk > qc.q_static ? tk - qc.q_static : 0u;
@@ -142,7 +142,8 @@ int main(int argc, char **argv) {
     c.tiles_y = 1 + static_cast<int>(rng() % 40);
     c.ns_log2 = (rng() & 1) ? 3 : 0;
     c.nframes = (c.ns_log2 == 0 && (rng() % 3) == 0) ? 1 + static_cast<int>(rng() % 5) : 1;
-    c.ds = static_cast<int>(rng() % 4);
+    c.ds = static_cast<int>(rng() % 7);
+    c.cap_log2 = static_cast<int>(rng() % 6);
     c.tpt = static_cast<int>(rng() % 5);
     c.deep_class = static_cast<int>(rng() % 5);
     c.waves = 32 * (1 + static_cast<int>(rng() % 40));   // workgroups of 4 waves, a multiple of 8 workgroups

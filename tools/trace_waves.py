@@ -17,9 +17,13 @@ for kv in sys.argv[4:]:
     k, v = kv.split("=")
     ctx.set_option(k, int(v))
 ps = R.prepare_scene(h, w, ctx.scene(scene))
-for _ in range(3):   # warm up + let the adaptive order settle
-    R.render(h, w, ps)
-rec = np.zeros((8192, 8), dtype=np.uint64)
+opts = dict(kv.split("=") for kv in sys.argv[4:])
+part, nparts = int(opts.get("trace_part", 0)), int(opts.get("trace_nparts", 1))
+buf = ctx.alloc_i32(h * w)
+for _ in range(3):   # warm up + let the adaptive order of the traced view settle
+    R.render_into(buf.ptr, h, w, ps, part=part, nparts=nparts)
+ctx.sync()
+rec = np.zeros((8192, 16), dtype=np.uint64)
 n = C.c_int32()
 ctx._check(lib.rt_render_trace(ctx._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
 rec = rec[: n.value].astype(np.int64)
@@ -42,7 +46,17 @@ tot = ops.sum(axis=1)
 print(f"  ops/wave: mean {tot.mean():.0f} max {tot.max()}  (BOX {ops[:,0].sum()} LEAF {ops[:,1].sum()} SHADE {ops[:,2].sum()})")
 print(f"  lane efficiency: BOX {items_box.sum() / (64.0 * ops[:,0].sum()):.3f} LEAF {items_leaf.sum() / (64.0 * ops[:,1].sum()):.3f}")
 print(f"  shader cycles per op (cycles lived / ops): mean {(rec[:, 4] / np.maximum(tot, 1)).mean():.0f}")
+n_t, n_b2 = rec[:, 5] & 0xFFFFFFFF, rec[:, 5] >> 32
+n_b1 = ops[:, 0] - n_t - n_b2
+cyc = rec[:, 8:13]   # BOX, BOX2, BOXT, LEAF, SHADE
+cnt = np.stack([n_b1, n_b2, n_t, ops[:, 1], ops[:, 2]], axis=1)
+names = ("BOX", "BOX2", "BOXT", "LEAF", "SHADE")
+print("  shader cycles per operation, by kind (all waves): " + ", ".join(
+    f"{nm} {cyc[:, k].sum() / max(cnt[:, k].sum(), 1):.0f} x {cnt[:, k].sum()}" for k, nm in enumerate(names))
+    + f"; between operations {(rec[:, 4].sum() - cyc.sum()) / max(tot.sum(), 1):.0f} per op")
 late = np.argsort(end)[-6:]
 for i in late[::-1]:
+    per = ", ".join(f"{nm} {cyc[i, k] / max(cnt[i, k], 1):.0f}x{cnt[i, k]}" for k, nm in enumerate(names))
     print(f"    wave {i:5d}: start {start[i]:7.1f} exhausted {exh[i]:7.1f} end {end[i]:7.1f} us; ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}")
+    print(f"                cycles/op: {per}; between ops {(rec[i, 4] - cyc[i].sum()) / max(tot[i], 1):.0f}")
 print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.1f} max {np.max(end - exh):.1f} us")
