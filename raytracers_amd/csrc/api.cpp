@@ -125,6 +125,7 @@ int get_uv(rt_context *ctx, int64_t w, int64_t h, const float **u, const float *
 struct Plan {
   int variant;
   int lds_nodes, lds_sph, smax, lmax, waves, grid;
+  int grid_full;   // every persistent workgroup (grid == grid_full unless grid_div says otherwise)
   int capb, capl, ray_planes;
   size_t lds_bytes;
 };
@@ -224,6 +225,38 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   // workgroups go round-robin to the 8 XCDs: keep their number a multiple of 8 so that no XCD carries
   // one more persistent workgroup than the others (grid_div=12 -> 42 workgroups measured +15 %)
   if (pl->grid >= 8) pl->grid -= pl->grid % 8;
+  pl->grid_full = std::max(1, ctx->num_cu * wgs);
+  if (pl->grid_full >= 8) pl->grid_full -= pl->grid_full % 8;
+  return 0;
+}
+
+// Which tiles of an ordered view are "deep" (their waves do not refill while they trace them) and in how many pieces the
+// deepest ones are handed out.  deep_class >= 0: as configured.  Auto (-1), from the view's class table (tiles with a bounce
+// chain of >= 32 / 16 / 8 scatters: read back once per view, the first time the view is rendered with its order):
+//   * a scene whose tiles with chains of >= 8 bounces would park only a few per cent of the launch's wave time if each of
+//     them kept a wave to itself (irreg: ~700 of 15 625 tiles; weight = sum of chain-length classes <= 2.5 per wave): all
+//     of them are deep, and the deepest waves / 64 tiles go out PIXEL BY PIXEL, one pixel per wave at launch, each traced
+//     by the solo loop (render_kernels.hip: solo_trace) -- the frame's longest chains get a whole wave each from t = 0;
+//     every persistent workgroup is launched (the chains no longer bound the frame, the work does);
+//   * otherwise (rgbbox: 141 tiles of >= 32 bounces, ~3 500 of >= 16): chains of >= 32 bounces are deep, the deepest
+//     waves / 128 tiles go out in quarters (round 2's setting; more held tiles cost more wave time than they save).
+struct DeepPolicy {
+  int deep_class, deep_split, cap_log2;
+  bool sparse;
+};
+int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves_full, DeepPolicy *dp) {
+  *dp = DeepPolicy{ctx->deep_class < 0 ? 3 : ctx->deep_class, ctx->deep_split, ctx->deep_cap_log2, false};
+  if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1) return 0;
+  if (!to->have_classes) {
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(to->classes, to->order + to->ntiles, sizeof to->classes, hipMemcpyDeviceToHost));
+    to->have_classes = true;
+  }
+  if (!ctx->solo || ps->tl_depth != rtk::kTreeletDepth) return 0;
+  const int64_t t3 = to->classes[3], t4 = to->classes[4], t5 = to->classes[5];
+  const int64_t w4 = 32 * t3 + 16 * (t4 - t3), w5 = w4 + 8 * (t5 - t4), budget = int64_t(5) * waves_full / 2;
+  if (w5 <= budget) *dp = DeepPolicy{5, 6, 0, true};
+  else if (w4 <= budget) *dp = DeepPolicy{4, 6, 0, true};
   return 0;
 }
 
@@ -319,6 +352,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
   p.tl_log2 = ps->tl_depth;
+  p.solo = ctx->solo;
   if (pl.variant == RT_VARIANT_POOLED) {
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
@@ -354,15 +388,19 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       const bool rerecord = !to->valid || ctx->adaptive_order == 2;
       p.cost = rerecord ? to->cost : nullptr;
       p.order = to->valid ? to->order : nullptr;
-      p.deep_class = ctx->deep_class;
-      p.deep_split = ctx->deep_split;
-      p.deep_cap_log2 = ctx->deep_cap_log2;
+      DeepPolicy dp;
+      if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
+      p.deep_class = dp.deep_class;
+      p.deep_split = dp.deep_split;
+      p.deep_cap_log2 = dp.cap_log2;
+      if (dp.sparse && ctx->grid_div == 0) pl.grid = pl.grid_full;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
       // next frames' ticket -> tile table from this frame's record (also clears the record)
       RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->stream));
       to->valid = true;
+      to->have_classes = false;
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
@@ -524,8 +562,10 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->adaptive_order = v;
   } else if (k == "box2") {
     ctx->box2 = v != 0;
+  } else if (k == "solo") {
+    ctx->solo = v != 0;
   } else if (k == "treelet") {
-    if (v < 1 || v > rtk::kTreeletMaxDepth) return fail(ctx, "treelet must be 1 (no treelets) .. 5 levels per treelet");
+    if (v < 1 || v > rtk::kTreeletMaxDepth) return fail(ctx, "treelet (host builder: levels per treelet) must be 1 .. 5");
     ctx->treelet = v;
   } else if (k == "trace_part") {
     ctx->trace_part = v;
@@ -535,7 +575,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     if (v != 0 && v != 2 && v != 3) return fail(ctx, "ray_planes must be 0 (auto), 2 or 3");
     ctx->ray_planes = v;
   } else if (k == "deep_class") {
-    ctx->deep_class = std::min(8, std::max(0, v));
+    ctx->deep_class = std::min(8, std::max(-1, v));   // -1: chosen per view (deep_policy)
   } else if (k == "deep_cap_log2") {
     ctx->deep_cap_log2 = std::min(8, std::max(0, v));
   } else if (k == "deep_split") {
@@ -671,6 +711,7 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
       rtk::GpuBvhOut o{ps->L7, ps->bmin, ps->bmax, ps->left, ps->right, ps->parent, ps->nodes, ps->nodes64, ps->sph, ps->col};
       e = rtk::gpu_build_bvh(scene_dev, static_cast<int>(n), o, tmp, ctx->pinned, ctx->stream, &ps->height, ps->root_lo,
                              ps->root_hi);
+      ps->tl_depth = rtk::kTreeletDepth;
     }
     if (tmp) {
       (void)hipStreamSynchronize(ctx->stream);
@@ -928,9 +969,11 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
       if (o.h == h && o.w == w && o.part == p.part && o.nparts == p.nparts && o.max_depth == max_depth && o.valid &&
           ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
         p.order = o.order;
-        p.deep_class = ctx->deep_class;
-        p.deep_split = ctx->deep_split;
-        p.deep_cap_log2 = ctx->deep_cap_log2;
+        DeepPolicy dp;
+        if (deep_policy(ctx, ps, &o, pl.grid_full * pl.waves, &dp)) rc = 1;
+        p.deep_class = dp.deep_class;
+        p.deep_split = dp.deep_split;
+        p.deep_cap_log2 = dp.cap_log2;
       }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -20,6 +20,7 @@
 #include <cstdint>
 
 #include "rt_device.hpp"
+#include "treelet.h"
 
 namespace rtk {
 namespace {
@@ -360,6 +361,64 @@ __global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int 
   if ((threadIdx.x & 63) == 0) atomicMax(maxdepth, d);
 }
 
+// ---- treelet-major numbering (treelet.h, cut of depth 2) ---------------------------------------
+// From the numbering by depth (order[t] = canonical node, depth_sorted[t] its depth, trav_of its inverse): a node of even
+// depth and its inner children become neighbours -- {node, left inner child, right inner child} -- and these treelets keep
+// the order of their roots, so the nodes nearest the root still form a prefix.  size[t] = nodes of the treelet rooted at the
+// t-th node (0 for a node of odd depth); its exclusive scan is where each treelet starts.
+__global__ __launch_bounds__(kBT) void treelet_size_kernel(const unsigned *depth_sorted, const int *order, const int *left,
+                                                           const int *right, int ni, unsigned *size) {
+  const int t = blockIdx.x * kBT + threadIdx.x;
+  if (t >= ni) return;
+  const int c = order[t];
+  size[t] = (depth_sorted[t] & 1u) ? 0u : 1u + (left[c] >= 0 ? 1u : 0u) + (right[c] >= 0 ? 1u : 0u);
+}
+constexpr int kScanE = 4;   // elements per thread of the multi-block scan
+__global__ __launch_bounds__(kBT) void scan_sums_kernel(const unsigned *v, int n, unsigned *sums) {
+  const int i0 = (blockIdx.x * kBT + threadIdx.x) * kScanE;
+  unsigned sum = 0;
+#pragma unroll
+  for (int e = 0; e < kScanE; ++e) sum += i0 + e < n ? v[i0 + e] : 0u;
+  unsigned long long tot;
+  (void)block_excl_scan_u64(sum, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = (unsigned)tot;
+}
+__global__ __launch_bounds__(kBT) void scan_apply_kernel(unsigned *v, int n, const unsigned *sums_excl) {   // in place, exclusive
+  const int i0 = (blockIdx.x * kBT + threadIdx.x) * kScanE;
+  unsigned x[kScanE], sum = 0;
+#pragma unroll
+  for (int e = 0; e < kScanE; ++e) {
+    x[e] = i0 + e < n ? v[i0 + e] : 0u;
+    sum += x[e];
+  }
+  unsigned long long tot;
+  unsigned run = sums_excl[blockIdx.x] + (unsigned)block_excl_scan_u64(sum, &tot);
+#pragma unroll
+  for (int e = 0; e < kScanE; ++e) {
+    if (i0 + e < n) v[i0 + e] = run;
+    run += x[e];
+  }
+}
+// a node's new index (+ its place in its treelet, packed: treelet.h) from the treelet starts
+__device__ __forceinline__ unsigned treelet_place(int c, const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
+                                                 const int *parent, const int *left, const int *right) {
+  const int t = trav_by_depth[c];
+  if (!(depth_sorted[t] & 1u)) return tl_pack_place(start[t], false, false, 0);
+  const int p = parent[c];
+  const bool is_right = right[p] == c;
+  const int pos = 1 + (is_right && left[p] >= 0 ? 1 : 0);
+  return tl_pack_place(start[trav_by_depth[p]] + (unsigned)pos, true, is_right, pos);
+}
+__global__ __launch_bounds__(kBT) void treelet_number_kernel(const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
+                                                             const int *parent, const int *left, const int *right, int ni,
+                                                             int *place, int *order) {
+  const int c = blockIdx.x * kBT + threadIdx.x;
+  if (c >= ni) return;
+  const unsigned pl = treelet_place(c, depth_sorted, start, trav_by_depth, parent, left, right);
+  place[c] = (int)pl;
+  order[pl & kTlIndexMask] = c;
+}
+
 __global__ __launch_bounds__(kBT) void invert_kernel(const int *order, int ni, int *trav_of) {
   const int t = blockIdx.x * kBT + threadIdx.x;
   if (t < ni) trav_of[order[t]] = t;
@@ -378,7 +437,7 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
     if (kid[k] <= -2) {
       ref[k] = ~(-2 - kid[k]);
     } else {
-      ref[k] = trav_of[kid[k]];
+      ref[k] = (int)((unsigned)trav_of[kid[k]] & kTlIndexMask);
       const float *mn = bmin + 3 * (size_t)kid[k], *mx = bmax + 3 * (size_t)kid[k];
       q[2 * k] = make_float4(mn[0], mn[1], mn[2], 0.f);
       q[2 * k + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
@@ -386,6 +445,9 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
   }
   q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted: a pooled work item is (reference << 8) | (slot * 4)
   q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
+  const TlMasks tm = tl_masks_depth2((unsigned)trav_of[c]);   // the node's place in its treelet (treelet.h)
+  q[2].w = __int_as_float((int)tm.l);
+  q[3].w = __int_as_float((int)tm.r);
   nodes64[4 * (size_t)t + 0] = q[0];
   nodes64[4 * (size_t)t + 1] = q[1];
   nodes64[4 * (size_t)t + 2] = q[2];
@@ -607,10 +669,52 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
   small_sort(lk, lv, ni, 6);
   __syncthreads();   // (the sort's last read-back is done)
   int *order = a.order, *trav_of = a.trav_of;   // global: LDS is about to hold the work lists
-  for (int t = tid; t < ni; t += kSmallNT) {
-    const int c = (int)lv[t];
-    order[t] = c;
-    trav_of[c] = t;
+  for (int t = tid; t < ni; t += kSmallNT) trav_of[(int)lv[t]] = t;
+  // ... then treelet by treelet (treelet.h; the multi-kernel path's treelet_size / scan / treelet_number in one block):
+  // lk[t] becomes the start of the treelet rooted at the t-th node of the order by depth, the depth's parity kept in bit 0
+  {
+    const int E = ((ni + kSmallNT - 1) / kSmallNT) | 1;
+    const int base = tid * E;
+    unsigned sz[kSmallE], sum = 0;
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e) {
+      sz[e] = 0;
+      if (e < E && base + e < ni) {
+        const int c = (int)lv[base + e];
+        sz[e] = (lk[base + e] & 1u) ? 0u : 1u + (a.o.left[c] >= 0 ? 1u : 0u) + (a.o.right[c] >= 0 ? 1u : 0u);
+        sum += sz[e];
+      }
+    }
+    unsigned long long tot;
+    unsigned run = (unsigned)block_excl_scan_u64<kSmallNT>(sum, &tot);   // (syncs: the by-depth inverse above is visible after it)
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < ni) {
+        lk[base + e] = (run << 1) | (lk[base + e] & 1u);
+        run += sz[e];
+      }
+    __syncthreads();
+    unsigned pl[kSmallE];
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < ni) {   // canonical node base + e
+        const int c = base + e, t = trav_of[c];
+        if (!(lk[t] & 1u)) {
+          pl[e] = tl_pack_place(lk[t] >> 1, false, false, 0);
+        } else {
+          const int p = a.o.parent[c];
+          const bool is_right = a.o.right[p] == c;
+          const int pos = 1 + (is_right && a.o.left[p] >= 0 ? 1 : 0);
+          pl[e] = tl_pack_place((lk[trav_of[p]] >> 1) + (unsigned)pos, true, is_right, pos);
+        }
+      }
+    __syncthreads();   // every by-depth index has been read
+#pragma unroll
+    for (int e = 0; e < kSmallE; ++e)
+      if (e < E && base + e < ni) {
+        trav_of[base + e] = (int)pl[e];                 // index + place, packed
+        order[pl[e] & kTlIndexMask] = base + e;
+      }
   }
   __syncthreads();
   STAMP(7);
@@ -716,12 +820,15 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
       const bool leaf = kid[k] <= -2;
       const size_t at = leaf ? 0 : (size_t)kid[k];
       const float4 l = fb[2 * at], h = fb[2 * at + 1];
-      ref[k] = leaf ? ~(-2 - kid[k]) : trav_of[at];
+      ref[k] = leaf ? ~(-2 - kid[k]) : (int)((unsigned)trav_of[at] & kTlIndexMask);
       q[2 * k] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(l.x, l.y, l.z, 0.f);
       q[2 * k + 1] = leaf ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(h.x, h.y, h.z, 0.f);
     }
     q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted (see trav_node)
     q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
+    const TlMasks tm = tl_masks_depth2((unsigned)trav_of[c]);
+    q[2].w = __int_as_float((int)tm.l);
+    q[3].w = __int_as_float((int)tm.r);
     a.o.nodes64[4 * (size_t)t + 0] = q[0];
     a.o.nodes64[4 * (size_t)t + 1] = q[1];
     a.o.nodes64[4 * (size_t)t + 2] = q[2];
@@ -904,8 +1011,20 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
     cur ^= 1;
   }
   hipLaunchKernelGGL(invert_kernel, dim3(nb_ni), dim3(kBT), 0, st, vals[cur], ni, trav_of);
-  hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, vals[cur], trav_of, o.left, o.right, o.bmin, o.bmax,
-                     ni, o.nodes32, o.nodes64);
+  // ... then treelet by treelet (treelet.h): sizes of the treelets in the order of their roots, their starts, the nodes' places
+  {
+    unsigned *start = keys[cur ^ 1];      // (free since the sort)
+    int *place = depth, *order2 = vals[cur ^ 1];
+    const int sb = cdiv(ni, kBT * kScanE);
+    hipLaunchKernelGGL(treelet_size_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], vals[cur], o.left, o.right, ni, start);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(sb), dim3(kBT), 0, st, start, ni, counts);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, sb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(sb), dim3(kBT), 0, st, start, ni, counts);
+    hipLaunchKernelGGL(treelet_number_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], start, trav_of, o.parent, o.left, o.right, ni,
+                       place, order2);
+    hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, order2, place, o.left, o.right, o.bmin, o.bmax, ni, o.nodes32,
+                       o.nodes64);
+  }
   hipLaunchKernelGGL(trav_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, o.L7, n, o.sph, o.col);
   BVH_HIP(hipGetLastError());
   BVH_HIP(hipMemcpyAsync(result, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));

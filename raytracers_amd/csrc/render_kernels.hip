@@ -356,12 +356,158 @@ __device__ __forceinline__ float pull(int lane_byte, float v) {   // v of the la
   return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_byte, __float_as_int(v)));
 }
 
+// ---------------------------------------------------------------------------------
+// SOLO: one ray, the whole wave.
+//
+// A frame cannot end before its longest bounce chain does (irreg 1000x1000: 10 pixels of 45-49 scatters, each scatter a
+// fold that depends on the one before), and in the pooled loop a wave that serves ONE ray still pays every operation's
+// general machinery: ~5 traversal operations + LEAF + SHADE per bounce at 1700-3900 shader cycles each = ~7 us per bounce
+// (profiles/r03/exp/e10_trace.txt).  When a wave that cannot refill (queue dry, or a held deep tile) is left with a single
+// live ray, it finishes that pixel here instead: the ray lives in registers (the same value in every lane), the fold is
+// a loop of TREELET operations -- 2^D lanes per popped treelet root, every lane tests the boxes of both children of one
+// node of the treelet speculatively, a node counts iff the boxes on its path inside the treelet passed (treelet.h: the
+// fixed (0, 1e9) box interval makes a box test independent of when it is made) -- and of sphere tests folded with one LDS
+// atomic min on the key format of the pooled loop; then the same shade_ray.  Same arithmetic, same (t, lowest leaf)
+// winner: bit-identical pixels.  A separate, never-inlined function: its registers are allocated on their own and the
+// pooled loop's are not disturbed (the pooled kernel measurably slows down when code is added to its loop).
+// Uses the wave's LDS region (hit key 0, box stack, leaf list, dump dword), which is idle when it is called.
+// ---------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) KParams *KParamsArg;   // the kernel's own argument block (scalar loads)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_load16(unsigned a) {
+  const v4f v = *reinterpret_cast<const __attribute__((address_space(3))) v4f *>(a);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ unsigned lds_load4(unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(a); }
+
+__device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned smem_lds, unsigned wbase_lds, float ox, float oy, float oz,
+                                                     float dx, float dy, float dz, float lr, float lg, float lb, int pix, int depth,
+                                                     int ptile) {
+  // (arguments arrive in vector registers: say that they are wave-uniform, or every load through `pp` is a vector load and
+  // every buffer_load a waterfall loop over its descriptor)
+  const unsigned long long pp_bits = (unsigned long long)pp_v;
+  KParamsArg pp = (KParamsArg)(((unsigned long long)(unsigned)uni((int)(pp_bits >> 32)) << 32) | (unsigned)uni((int)pp_bits));
+  smem_lds = (unsigned)uni((int)smem_lds); wbase_lds = (unsigned)uni((int)wbase_lds);
+  pix = uni(pix); depth = uni(depth); ptile = uni(ptile);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int plane16 = 16 * pp->lds_nodes;             // bytes of one node plane
+  const int n_nodes16 = 16 * pp->n_nodes, lds_sph = pp->lds_sph;
+  const unsigned sph_lds = smem_lds + 4u * (unsigned)plane16;
+  const unsigned key_lds = wbase_lds, dump_lds = wbase_lds + 768u;
+  const unsigned box_lds = wbase_lds + 4u * (unsigned)(kPooledWaveFixedDw + 256 * pp->ray_planes);
+  const unsigned leaf_lds = box_lds + 4u * (unsigned)pp->capb;
+  const __amdgpu_buffer_rsrc_t rs_nodes = make_rsrc(pp->nodes64, (unsigned)pp->n_nodes * 64u);
+  const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(pp->sph, (unsigned)pp->n_sph * 16u);
+  const __amdgpu_buffer_rsrc_t rs_col = make_rsrc(pp->col, (unsigned)pp->n_sph * 16u);
+  const int max_depth = pp->max_depth;
+  const float rlx = pp->root_lo[0], rly = pp->root_lo[1], rlz = pp->root_lo[2];
+  const float rhx = pp->root_hi[0], rhy = pp->root_hi[1], rhz = pp->root_hi[2];
+  auto key_ptr = reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(key_lds);
+  Ray r;
+  r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+  for (;;) {   // one ray of the pixel's chain per iteration
+    ray_derive(r);
+    unsigned long long key = kKeyInit;
+    if (box_hit(r, rlx, rly, rlz, rhx, rhy, rhz)) {   // (uniform: every lane holds the same ray)
+      if (lane == 0) {
+        *key_ptr = kKeyInit;
+        lds_store((int)box_lds, 0u);                  // the root: a treelet root whose box passed
+      }
+      int nbox = 1, nleaf = 0;
+      while ((nbox | nleaf) != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (nleaf >= 64 || nbox == 0) {
+          // ---- sphere tests: up to 64 leaves ----
+          const int top = nleaf - 1 - lane;
+          const unsigned item = lds_load4(leaf_lds + 4u * (unsigned)(top < 0 ? 0 : top));
+          const bool act = top >= 0;
+          nleaf = uni(nleaf > 64 ? nleaf - 64 : 0);
+          const int jj = act ? ~((int)item >> 8) : 0;
+          float4 s = lds_load16(sph_lds + 16u * (unsigned)(jj < lds_sph ? jj : 0));
+          if (jj >= lds_sph) s = buf_load16(rs_sph, jj * 16);
+          bool near_root;
+          const float g = sphere_root_flag(r, s.x, s.y, s.z, s.w, &near_root);
+          if (act & (g < kTMax))
+            __hip_atomic_fetch_min(key_ptr, ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+          // ---- treelet operation (treelet.h, cut of depth kTreeletDepth): up to 64 >> D roots, 2^D lanes each ----
+          // lane `pos` of a group reads the record of the treelet's node at that position -- whatever record is there: its
+          // masks tell -- and tests the boxes of BOTH its children, speculatively; the node was REACHED iff every box on its
+          // path from the treelet's root passed (the masks name the lanes that tested them).  Reached nodes append their leaf
+          // children to the leaf list and, on the treelet's last level, their passing inner children (the next roots).
+          constexpr int D = kTreeletDepth;
+          const int pos = lane & ((1 << D) - 1), gsh = lane & ~((1 << D) - 1);
+          const int top = nbox - 1 - (lane >> D);
+          const unsigned item = lds_load4(box_lds + 4u * (unsigned)(top < 0 ? 0 : top));
+          const bool has = top >= 0;
+          nbox = uni(nbox > (64 >> D) ? nbox - (64 >> D) : 0);
+          int ni16 = (int)((item >> 4) & 0xfffffff0u) + 16 * pos;
+          ni16 = ni16 < n_nodes16 ? ni16 : 0;
+          const bool res = ni16 < plane16;
+          const unsigned a0 = smem_lds + (unsigned)(res ? ni16 : 0);
+          float4 q0 = lds_load16(a0), q1 = lds_load16(a0 + (unsigned)plane16), q2 = lds_load16(a0 + 2u * (unsigned)plane16),
+                 q3 = lds_load16(a0 + 3u * (unsigned)plane16);
+          if (!res) {
+            q0 = buf_load16(rs_nodes, ni16 * 4);
+            q1 = buf_load16(rs_nodes, ni16 * 4 + 16);
+            q2 = buf_load16(rs_nodes, ni16 * 4 + 32);
+            q3 = buf_load16(rs_nodes, ni16 * 4 + 48);
+          }
+          const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);
+          const unsigned ml = (unsigned)f2i(q2.w), mr = (unsigned)f2i(q3.w);
+          const unsigned long long m_hl = bal(box_hit(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
+          const unsigned long long m_hr = bal(box_hit(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+          const bool reach = has && tl_reached(ml, mr, pos, (unsigned)(m_hl >> gsh), (unsigned)(m_hr >> gsh));
+          const unsigned long long m_reach = bal(reach), m_exit = m_reach & bal(tl_frontier(ml));
+          const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
+          const unsigned long long m_inl = m_exit & ~m_ln & m_hl, m_inr = m_exit & ~m_rn & m_hr;
+          const unsigned long long m_lfl = m_reach & m_ln, m_lfr = m_reach & m_rn;
+          const int c_inl = __popcll(m_inl), c_lfl = __popcll(m_lfl);
+          const int b_box = (int)box_lds + 4 * nbox, b_leaf = (int)leaf_lds + 4 * nleaf, dump = (int)dump_lds;
+          const int a_l = sel_mask(m_lfl, sel_mask(m_inl, dump, b_box + 4 * lane_rank(m_inl)), b_leaf + 4 * lane_rank(m_lfl));
+          const int a_r = sel_mask(m_lfr, sel_mask(m_inr, dump, b_box + 4 * lane_rank_from(m_inr, c_inl)),
+                                   b_leaf + 4 * lane_rank_from(m_lfr, c_lfl));
+          lds_store(a_l, (unsigned)cl8);
+          lds_store(a_r, (unsigned)cr8);
+          nbox = uni(nbox + c_inl + __popcll(m_inr));
+          nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      key = *key_ptr;
+    }
+    // ---- the rest of ray_colour's iteration, as in the pooled loop's SHADE ----
+    const float best = __uint_as_float((unsigned)(key >> 32));
+    const bool hit = key != kKeyInit;
+    const int wj = hit ? (int)((unsigned)key >> 1) : 0;
+    float4 c = buf_load16(rs_col, wj * 16);
+    float4 s = lds_load16(sph_lds + 16u * (unsigned)(wj < lds_sph ? wj : 0));
+    if (wj >= lds_sph) s = buf_load16(rs_sph, wj * 16);
+    if (!hit) {
+      s = make_float4(0.f, 0.f, 0.f, 1.f);
+      c = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool have = hit;
+    float t = best;
+    if (hit && !rehit_is_best(best, ((unsigned)key & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
+    int32_t pixel;
+    if (!shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, max_depth, &pixel)) {
+      if (lane == 0) {
+        pp->out[pix] = pixel;
+        if (pp->cost != nullptr && depth >= 2) atomicMax(&pp->cost[ptile], depth + 1);
+      }
+      return;
+    }
+  }
+}
+
 // Work items are one dword: (reference << 8) | (slot * 4); `reference` is an inner node index
 // (box stack) or ~leaf index (leaf list), both < 2^23.
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
-template <int THREADS, bool ALL_LDS, bool STATS>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -443,6 +589,44 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     tr_c0 = clock64();
   }
 
+  // SOLO pixels: while this wave's tickets are single pixels of the deepest tiles (rt_device.hpp: ticket_span; the first
+  // tickets of the launch, most of them static), each is traced by solo_trace with the whole wave behind it.  HERE, ahead
+  // of the pooled loop: a call inside the loop cost the whole kernel 4-7 % (registers saved around it, scalar spills).
+  // (its own instantiation: with the call compiled in, the loop behind it runs 1-5 % slower -- scalar registers saved around
+  // the call stay spilled -- so launches without single-pixel tickets use the kernel without it)
+  if (SOLO && deep_on && p.deep_split == 6 && p.tl_log2 == kTreeletDepth) {
+    for (;;) {
+      TicketSpan sp;
+      const QueueConst qc = queue_const();
+      const unsigned wave_rank = (unsigned)uni((int)((unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2)));
+      const bool got = queue_draw(q_state, qc, wave_rank, [&](int shard) {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(&p.queue[kQueueStride * shard], 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane(v);
+      }, &sp);
+      if (!got) {
+        exhausted = true;
+        break;
+      }
+      if (sp.q_end - sp.q_next != 1u) {   // a tile (or a larger piece): the pooled loop's
+        q_next = sp.q_next;
+        q_end = sp.q_end;
+        q_enter = true;
+        break;
+      }
+      const int tile = p.order[sp.q_next >> 6], within = (int)(sp.q_next & 63u);
+      const int ty = tile / p.tiles_x;
+      const int col = (tile - ty * p.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+      if (col < p.w && lrow < p.rows_local) {
+        const int k = lrow >> p.rpt_log2;
+        const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+        Ray pr;
+        primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
+        solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+                   pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col, 0, tile);
+      }
+    }
+  }
   for (;;) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
@@ -1013,10 +1197,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1026,21 +1210,28 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
+  // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
+  const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
+#define RT_POOLED_CASE(W)                                                                                               \
+  case W:                                                                                                               \
+    return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \
+                   : (solo ? launch_pooled_t<64 * W, false, false, true>(p, grid, stream) : launch_pooled_t<64 * W, false, false>(p, grid, stream));
   switch (waves_per_wg) {
-  case 4: return all_lds ? launch_pooled_t<256, true, false>(p, grid, stream) : launch_pooled_t<256, false, false>(p, grid, stream);
-  case 8: return all_lds ? launch_pooled_t<512, true, false>(p, grid, stream) : launch_pooled_t<512, false, false>(p, grid, stream);
-  case 12: return all_lds ? launch_pooled_t<768, true, false>(p, grid, stream) : launch_pooled_t<768, false, false>(p, grid, stream);
-  case 16: return all_lds ? launch_pooled_t<1024, true, false>(p, grid, stream) : launch_pooled_t<1024, false, false>(p, grid, stream);
+    RT_POOLED_CASE(4)
+    RT_POOLED_CASE(8)
+    RT_POOLED_CASE(12)
+    RT_POOLED_CASE(16)
   default: return hipErrorInvalidValue;
   }
+#undef RT_POOLED_CASE
 }
 
 // Loads this file's code object and resolves the default kernels (HIP loads modules lazily, at
 // the first launch: ~0.5 ms that would otherwise land in the first timed frame).
 void warm_render_kernels() {
   hipFuncAttributes a;
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<768, true, false>);
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false>);
   (void)hipFuncGetAttributes(&a, (const void *)tile_order_kernel);
 }
 

@@ -189,6 +189,7 @@ struct KParams {
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
+  int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)
   int deep_class;        // a shard's positions below its class table's entry [deep_class] are "deep" tiles (0: feature off)
   int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)

@@ -33,14 +33,15 @@ struct rt_context {
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
-  int treelet = 1;          // prepare_scene cuts the traversal copy into treelets of this many levels (treelet.h; 1: none)
+  int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
+  int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)
   int trace_part = 0, trace_nparts = 1;   // rt_render_trace: which part of the row-tile partition the instrumented launch renders
   int ray_planes = 0;       // pooled family: planes of the LDS ray table (0 = chosen with the workgroup shape, 2, 3)
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
   int prio_depth = 4;       // pooled family: s_setprio steps at 1x/2x/4x this bounce depth (0: off)
   int grid_div = 0;         // persistent families: launch (CUs * wgs_per_cu) / grid_div workgroups; 0 = by frame size
   int adaptive_order = 1;   // pooled family: order tiles by the previous frame's bounce-chain record
-  int deep_class = 3;       // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off)
+  int deep_class = -1;      // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off; -1: chosen per view together with deep_split / deep_cap_log2, api.cpp: deep_policy)
   int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
   int deep_cap_log2 = 5;    // ... while the pieces occupy at most one in 2^this of the launch's waves
   int xcd_queues = -1;      // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp); -1: frames of >= 32768 tiles
@@ -96,6 +97,8 @@ struct TileOrder {
   int *cost = nullptr;    // [ntiles] record written by the render kernel
   int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
+  bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
+  int classes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct rt_prepared {

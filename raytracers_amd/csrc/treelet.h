@@ -34,6 +34,7 @@
 namespace rtk {
 
 constexpr int kTreeletMaxDepth = 5;             // 2^5 - 1 = 31 nodes: positions fit bits 0..30
+constexpr int kTreeletDepth = 2;                // the cut both builders make: a node of even depth + its inner children
 constexpr uint32_t kTlFrontier = 0x80000000u;   // in mask_l
 constexpr uint32_t kTlPosBits = 0x7fffffffu;
 
@@ -56,6 +57,21 @@ RT_TL_HD TlMasks tl_masks(uint32_t occ, int h, int D) {
   }
   if (h >= (1 << (D - 1)) - 1) m.l |= kTlFrontier;
   return m;
+}
+
+// The GPU builder (bvh_build.hip) numbers the cut of depth 2 without the general machinery: a node of odd depth sits
+// right behind its parent (position 1, or 2 for a right child whose left sibling is an inner node too).  It carries a
+// node's place next to its traversal index: index in bits 0..23, then odd depth, right child, position (2 bits).
+constexpr int kTlIndexBits = 24;
+constexpr uint32_t kTlIndexMask = (1u << kTlIndexBits) - 1u;
+RT_TL_HD uint32_t tl_pack_place(uint32_t index, bool odd, bool is_right, int pos) {
+  return index | (odd ? 1u << kTlIndexBits : 0u) | (is_right ? 2u << kTlIndexBits : 0u) | ((uint32_t)pos << (kTlIndexBits + 2));
+}
+RT_TL_HD TlMasks tl_masks_depth2(uint32_t place) {   // == tl_masks(occ, heap index, 2) for that node
+  const bool odd = (place >> kTlIndexBits) & 1u, is_right = (place >> (kTlIndexBits + 1)) & 1u;
+  const uint32_t self = 1u << ((place >> (kTlIndexBits + 2)) & 3u);
+  if (!odd) return TlMasks{self, self};
+  return TlMasks{self | (is_right ? 0u : 1u) | kTlFrontier, self | (is_right ? 1u : 0u)};
 }
 
 // kernel side: lane at position `pos` of its group read masks (ml, mr); hl / hr are the group's bits (bit p = the lane at
