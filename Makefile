@@ -12,15 +12,15 @@ HOSTFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
 
 all: $(LIB) tools oracle
 
-$(OBJ)/render_kernels.o: $(CSRC)/render_kernels.hip $(CSRC)/lane_core.h $(CSRC)/rt_device.hpp
+$(OBJ)/render_kernels.o: $(CSRC)/render_kernels.hip $(CSRC)/lane_core.h $(CSRC)/rt_device.hpp $(CSRC)/treelet.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJ)/bvh_build.o: $(CSRC)/bvh_build.hip $(CSRC)/rt_device.hpp $(CSRC)/lane_core.h
+$(OBJ)/bvh_build.o: $(CSRC)/bvh_build.hip $(CSRC)/rt_device.hpp $(CSRC)/lane_core.h $(CSRC)/treelet.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_internal.hpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h
+$(OBJ)/api.o: $(CSRC)/api.cpp $(CSRC)/rt_internal.hpp $(CSRC)/rt_device.hpp $(CSRC)/rt_host.hpp $(CSRC)/lane_core.h include/ray.h include/rt_mi355x.h $(CSRC)/treelet.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -28,7 +28,7 @@ $(OBJ)/multi_gpu.o: $(CSRC)/multi_gpu.cpp $(CSRC)/rt_internal.hpp $(CSRC)/rt_dev
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJ)/host_build.o: $(CSRC)/host_build.cpp $(CSRC)/rt_host.hpp
+$(OBJ)/host_build.o: $(CSRC)/host_build.cpp $(CSRC)/rt_host.hpp $(CSRC)/treelet.h
 	@mkdir -p $(OBJ)
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
@@ -55,7 +55,12 @@ build/queue_check: tools/queue_check.cpp $(CSRC)/rt_device.hpp $(CSRC)/lane_core
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Wall -I$(CSRC) -o $@ $<
 
-tools: build/rtbench build/issue_peak build/queue_check
+# design tool + CPU check of the treelet numbering / masks (treelet.h) against a plain depth-first walk; in the CPU test suite
+build/treelet_probe: tools/treelet_probe.cpp $(CSRC)/lane_core.h $(CSRC)/treelet.h $(CSRC)/rt_host.hpp $(OBJ)/host_build.o
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -I$(CSRC) -o $@ tools/treelet_probe.cpp $(OBJ)/host_build.o
+
+tools: build/rtbench build/issue_peak build/queue_check build/treelet_probe
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -157,46 +157,89 @@ def test_big_2000_at_size(R, ctx):
     mc.close()
 
 
-@pytest.mark.parametrize("treelet", [1, 2, 3, 4, 5])
-def test_treelet_numbering_does_not_change_pixels(R, treelet):
-    """The traversal copy numbered treelet by treelet (treelet.h) under every cut depth: frames, a part of three, a
-    batch, on the reference scenes, another tree shape and a scene with duplicates."""
-    import torch
-    c = R.Context()
-    c.set_variant(3)
-    c.set_option("treelet", treelet)
+def _solo_cases():
     rng = np.random.default_rng(5)
     s = np.zeros((700, 7), np.float32)
     s[:, 0:3] = rng.uniform(-40, 40, (700, 3))
     s[:, 3:6] = rng.uniform(0.2, 1.0, (700, 3))
     s[:, 6] = rng.uniform(0.5, 6.0, 700)
-    s[100:160, 0:3] = s[0:60, 0:3]
-    s[200:260] = s[300:360]
-    lf, la, fov = (5.0, 25.0, 70.0), (0.0, 0.0, 0.0), 60.0
-    cases = [("rgbbox", None, 333, 250), ("irreg", None, 200, 280), ("floor:37:222", None, 90, 120),
-             ("custom", O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov), 150, 200)]
-    for gpu_build in (0, 1):
-        c.set_option("gpu_build", gpu_build)
-        for name, orc, h, w in cases:
-            orc = orc or _oracle(name)
-            want, cnt = orc.render(h, w)
-            sc = c.scene_from_spheres(s, lf, la, fov) if name == "custom" else _scene(c, name)
-            ps = R.prepare_scene(h, w, sc)
-            for frame in range(3):   # cold view, ordered view with deep tiles, again
-                got = R.render(h, w, ps)
-                assert int((got != want).sum()) == 0, (name, gpu_build, frame)
-            buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+    s[100:160, 0:3] = s[0:60, 0:3]          # coincident centres
+    s[200:260] = s[300:360]                 # exact duplicates
+    two = np.zeros((2, 7), np.float32)      # one inner node: a treelet of one
+    two[:, 0] = (-4.0, 4.0); two[:, 3:6] = 0.8; two[:, 6] = 3.0
+    pts = [(1023.0, 1023.0, 1023.0)] + [tuple(float(2 ** m) if a == k else 0.0 for k in range(3)) for a in range(3) for m in range(10)]
+    tall = np.zeros((len(pts) + 64, 7), np.float32)   # a 30-level chain + 64 duplicates: height 36
+    tall[:len(pts), 0:3] = np.array(pts, np.float32)
+    tall[:, 3:6] = 0.7; tall[:, 6] = 0.4
+    return [("rgbbox", None, 333, 250), ("irreg", None, 200, 280), ("floor:37:222", None, 90, 120), ("floor:300:1800", None, 120, 160),
+            ("custom", (s, (5.0, 25.0, 70.0), (0.0, 0.0, 0.0), 60.0), 150, 200),
+            ("custom", (two, (0.0, 3.0, 30.0), (0.0, 0.0, 0.0), 50.0), 72, 96),
+            ("custom", (tall, (30.0, 20.0, 60.0), (0.0, 0.0, 0.0), 40.0), 90, 120)]
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(deep_class=8, deep_split=6, deep_cap_log2=0), dict(deep_class=8, deep_split=6, deep_cap_log2=0, grid_div=16),
+                                  dict(deep_class=5, deep_split=6, deep_cap_log2=2, xcd_queues=1), dict(deep_class=8, deep_split=6, deep_cap_log2=0, static_first=0),
+                                  dict(deep_class=8, deep_split=6, deep_cap_log2=0, solo=0), dict(deep_class=4, deep_split=5, deep_cap_log2=1)])
+@pytest.mark.parametrize("gpu_build", [1, 0])
+def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
+    """Single-pixel tickets traced by the solo loop (render_kernels.hip: solo_trace -- treelet operations on the traversal
+    copy numbered treelet by treelet, by both builders): the view's chosen policy (default), every recorded tile handed out
+    pixel by pixel (more tickets than waves with grid_div=16: the solo prologue also draws from the counters), strips, no
+    static first tickets, the same tickets through the pooled loop (solo=0).  Frames of a view (recording, ordered),
+    a part of three and a batch, buffers poisoned: reference scenes, 90 000 spheres (the multi-kernel builder), duplicates,
+    a single inner node, a 36-level tree."""
+    import torch
+    from raytracers_amd.dist import tile_rows
+    c = R.Context()
+    c.set_variant(3)
+    c.set_option("gpu_build", gpu_build)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    for name, custom, h, w in _solo_cases():
+        if custom is None:
+            orc, sc = _oracle(name), _scene(c, name)
+        else:
+            orc = O.OracleScene("custom", spheres7=custom[0], look_from=custom[1], look_at=custom[2], fov=custom[3])
+            sc = c.scene_from_spheres(*custom)
+        want, _ = orc.render(h, w)
+        ps = R.prepare_scene(h, w, sc)
+        out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        for frame in range(4):
+            out.fill_(-1)
             torch.cuda.synchronize()
-            R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+            R.render_into(out.data_ptr(), h, w, ps)
             c.sync()
-            assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, gpu_build, "batch")
-            part = torch.full((R.part_rows(h, 1, 3), w), -3, dtype=torch.int32, device="cuda")
+            assert int((out.cpu().numpy() != want).sum()) == 0, (name, frame)
+        part = torch.empty((R.part_rows(h, 1, 3), w), dtype=torch.int32, device="cuda")
+        for frame in range(3):
+            part.fill_(-3)
             torch.cuda.synchronize()
             R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
             c.sync()
-            from raytracers_amd.dist import tile_rows
-            assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, gpu_build, "part")
-            ps.free()
+            assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, "part", frame)
+        buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+        c.sync()
+        assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch")
+        ps.free()
+    c.close()
+
+
+@pytest.mark.parametrize("treelet", [1, 3, 4, 5])
+def test_host_builder_other_treelet_cuts(R, treelet):
+    """The host builder's numbering under other cuts than the shipped one (treelet.h; the solo loop is off then): the
+    pooled loop does not care how the traversal copy is numbered."""
+    c = R.Context()
+    c.set_variant(3)
+    c.set_option("gpu_build", 0)
+    c.set_option("treelet", treelet)
+    for name in ("rgbbox", "irreg", "floor:37:222"):
+        want, _ = _oracle(name).render(96, 120)
+        ps = R.prepare_scene(96, 120, _scene(c, name))
+        for frame in range(2):
+            assert int((R.render(96, 120, ps) != want).sum()) == 0, (name, frame)
+        ps.free()
     c.close()
 
 

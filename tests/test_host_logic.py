@@ -120,6 +120,18 @@ def test_tile_queue_protocol_on_the_cpu():
         assert "random cases" in out.stdout and "passed" in out.stdout
 
 
+@pytest.mark.parametrize("scene,size", [("rgbbox", "96"), ("irreg", "96"), ("23", "64")])
+def test_treelet_numbering_and_masks_on_the_cpu(scene, size):
+    """tools/treelet_probe redoes every fold of a small frame from the 64-byte records of the traversal copy cut into
+    treelets of 2 (the shipped cut) .. 5 levels, decoding the masks with the solo loop's own helpers (treelet.h) on emulated
+    lanes: each fold must meet exactly the leaves the depth-first walk of the same tree meets."""
+    exe = os.path.join(ROOT, "build", "treelet_probe")
+    subprocess.run(["make", "-s", "build/treelet_probe"], cwd=ROOT, check=True)
+    out = subprocess.run([exe, scene, size, "0"], capture_output=True, text=True)
+    assert out.returncode == 0 and "treelet check OK" in out.stdout, out.stdout + out.stderr
+    assert out.stdout.count("same leaf sets from the records") == 4
+
+
 def test_reference_harness_builds_against_our_header():
     """/root/reference/futhark/main.c must compile and link unmodified (build container only)."""
     if not os.path.exists("/root/reference/futhark/main.c"):

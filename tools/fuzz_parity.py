@@ -55,16 +55,16 @@ while time.time() < t_end:
     ok = True
     # random launch knobs (must never change pixels)
     knobs = dict(grid_div=int(rng.choice([0, 1, 2, 4, 8, 16])), thr_shade=int(rng.choice([1, 8, 24, 48, 64])),
-                 deep_class=int(rng.integers(0, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
+                 deep_class=int(rng.integers(-1, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
                  lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])),
                  wgs_per_cu=int(rng.choice([1, 2, 4])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])),
-                 deep_split=int(rng.integers(0, 4)),
+                 deep_split=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 6, 6])), deep_cap_log2=int(rng.integers(0, 6)), solo=int(rng.choice([0, 1, 1, 1])),
                  # the tile queue: one counter / a strip of tile columns per counter / counters taking turns, tiles per ticket,
                  # the waves' first tickets without an atomic
                  xcd_queues=int(rng.choice([-1, 0, 1, 2])), tpt_log2=int(rng.choice([-1, -1, 0, 1, 2, 3, 4])),
                  static_first=int(rng.choice([0, 1, 1])),
-                 # the treelet cut of the traversal copy (levels per treelet: the numbering must never matter)
-                 treelet=int(rng.integers(1, 6)))
+                 # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
+                 treelet=int(rng.choice([2, 2, 2, 1, 4])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):

@@ -7,7 +7,11 @@
 // node counts as reached iff the boxes on its path inside the treelet passed.  Uses the product's host BVH builder and
 // lane_core.h, on the rays of the long bounce chains of a frame (they bound a frame's time).
 //
-//   build/treelet_probe <rgbbox|irreg> <size> [min_chain]
+// It is also the CPU CHECK of the numbering and the masks (tests/test_host_logic.py): every fold is redone from the 64-byte
+// records of the layouts cut at D = 2 .. 5 with the kernel's own decoding (treelet.h: tl_reached / tl_frontier) on emulated
+// lanes, and must meet exactly the leaves the plain depth-first walk meets.
+//
+//   build/treelet_probe <rgbbox|irreg|n (a floor of n x n spheres)> <size> [min_chain]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -186,7 +190,7 @@ int main(int argc, char **argv) {
         std::vector<int> lv;
         ops_b2 += fold_ops_box2(T, q, lv);
         nleaves += lv.size();
-        for (int D = 3; D <= 6; ++D) {
+        for (int D = 2; D <= 6; ++D) {
           std::vector<int> lv2;
           ops_t[D] += fold_ops_treelet(T, q, D, lv2, &max_items[D]);
           if (lv2.size() != lv.size()) { printf("leaf set mismatch\n"); return 1; }
@@ -202,7 +206,7 @@ int main(int argc, char **argv) {
     }
   printf("  %llu chains, %llu folds (root box passed), %.1f leaf items per fold\n", chains, folds, (double)nleaves / folds);
   printf("  BOX2 (<= 32 items, 2 levels / op):   %.2f ops per fold\n", (double)ops_b2 / folds);
-  for (int D = 3; D <= 6; ++D)
+  for (int D = 2; D <= 6; ++D)
     printf("  treelets D=%d (%2d lanes, %d items / op): %.2f ops per fold (most items on the stack: %d)%s\n", D, 1 << D, 64 >> D, (double)ops_t[D] / folds, max_items[D],
            D <= rtk::kTreeletMaxDepth ? "; same leaf sets from the records" : "");
   printf("treelet check OK\n");
