@@ -112,7 +112,9 @@ int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int
  * again as the reference's harness does, main.c:107-124).  Frame f is traced through cams12 + 12 f (host memory; NULL:
  * the prepared camera for every frame) into out_dev + f * frame_stride (int32 elements, >= rows * w).  The persistent
  * waves run straight across frame boundaries, so a launch's fill and drain are paid once per batch instead of once
- * per frame.  Partition arguments as rt_render_part; not available on a multi-device context. */
+ * per frame.  Partition arguments as rt_render_part.  The array at cams12 is copied before the call returns.
+ * On a multi-device context (part 0 of 1 only): every device renders its row tiles of ALL the frames in one launch, the
+ * framebuffer gather moves nframes x part per device, one assembly launch writes the nframes images. */
 int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                     int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride, int32_t *out_dev);
 int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);
@@ -129,6 +131,13 @@ int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile,
  * gathered buffer may carry the parts of several frames (one gather per step, see dist.py). */
 int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts,
                            int64_t part_stride, const int32_t *stacked_dev, int32_t *image_dev);
+
+/* ... and of a batch, in one launch: frame f's parts lie frame_stride_in elements behind frame f - 1's inside every
+ * part (part_stride >= (nframes - 1) * frame_stride_in + the largest part), its image frame_stride_out (>= h * w)
+ * elements behind the previous one at images_dev. */
+int rt_place_parts_batch(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t part_stride,
+                         int32_t nframes, int64_t frame_stride_in, int64_t frame_stride_out, const int32_t *stacked_dev,
+                         int32_t *images_dev);
 
 /* Work counters of one frame, computed on the device by an instrumented launch of the
  * same traversal: rays (objs_hit calls), box tests, sphere tests. */

@@ -18,7 +18,7 @@ RT_SYMBOLS = [
     "rt_scene_free",
     "rt_prepare_scene", "rt_prepared_free", "rt_prepared_num_spheres", "rt_prepared_height", "rt_prepared_get_bvh",
     "rt_prepared_get_camera",
-    "rt_render", "rt_render_part", "rt_render_image", "rt_render_batch", "rt_part_rows", "rt_place_part", "rt_place_parts", "rt_place_parts_strided", "rt_render_stats", "rt_render_trace",
+    "rt_render", "rt_render_part", "rt_render_image", "rt_render_batch", "rt_part_rows", "rt_place_part", "rt_place_parts", "rt_place_parts_strided", "rt_place_parts_batch", "rt_render_stats", "rt_render_trace",
     "rt_render_timed",
     "rt_device_alloc", "rt_device_free", "rt_copy_to_host",
 ]
@@ -83,6 +83,7 @@ def _load():
         "rt_place_part": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, vp]),
         "rt_place_parts": (C.c_int, [vp, i64, i64, i32, i32, i64, vp, vp]),
         "rt_place_parts_strided": (C.c_int, [vp, i64, i64, i32, i32, i64, vp, vp]),
+        "rt_place_parts_batch": (C.c_int, [vp, i64, i64, i32, i32, i64, i32, i64, i64, vp, vp]),
         "rt_render_stats": (C.c_int, [vp, vp, i64, i64, i32, vp]),
         "rt_render_trace": (C.c_int, [vp, vp, i64, i64, i32, vp, i32, C.POINTER(i32)]),
         "rt_render_timed": (C.c_int, [vp, vp, i64, i64, i32, i32, i32, i32, vp, i32, i32, vp]),

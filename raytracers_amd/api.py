@@ -301,3 +301,13 @@ def place_parts(ctx, h, w, nparts, pad_rows, stacked_ptr, image_ptr, rows_per_ti
     else:
         ctx._check(lib.rt_place_parts_strided(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(part_stride),
                                               C.c_void_p(stacked_ptr), C.c_void_p(image_ptr)))
+
+
+def place_parts_batch(ctx, h, w, nparts, part_stride, nframes, frame_stride_in, stacked_ptr, images_ptr, frame_stride_out=None,
+                      rows_per_tile=ROWS_PER_TILE):
+    """All gathered parts of `nframes` frames -> nframes h x w images, ONE kernel (rt_place_parts_batch): inside part p
+    (at stacked_ptr + 4 * p * part_stride) frame f's packed rows start f * frame_stride_in elements in; image f at
+    images_ptr + 4 * f * frame_stride_out (default h * w)."""
+    ctx._check(lib.rt_place_parts_batch(ctx._h, int(h), int(w), int(rows_per_tile), int(nparts), int(part_stride), int(nframes),
+                                        int(frame_stride_in), int(h * w if frame_stride_out is None else frame_stride_out),
+                                        C.c_void_p(stacked_ptr), C.c_void_p(images_ptr)))

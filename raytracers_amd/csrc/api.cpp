@@ -480,6 +480,8 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
     (void)hipFree(t.v);
   }
   if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
+  if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
+  if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
@@ -822,29 +824,50 @@ extern "C" int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t
 
 // N frames of one prepared scene in ONE launch of the pooled kernel (its ticket queue simply runs over the tiles of
 // all frames, so the waves stay full across frame boundaries and the launch's fill and drain are paid once).
+// The batch's cameras on the context's device.  The caller's array is copied into the context's own pinned block first:
+// the asynchronous upload then never reads memory the caller may already have changed or freed (pinned caller memory
+// would otherwise be read when the copy EXECUTES).
+int rti::stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const float **cams_dev) {
+  *cams_dev = nullptr;
+  if (!cams12) return 0;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float) * 12 * static_cast<size_t>(nframes);
+  if (bytes > ctx->cams_bytes) {
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
+  if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
+  if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
+    if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
+    ctx->cams_dev = nullptr;
+    ctx->cams_host = nullptr;
+    ctx->cams_bytes = 0;
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cams_dev), bytes));
+    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->cams_host), bytes, hipHostMallocDefault));
+    ctx->cams_bytes = bytes;
+  } else if (ctx->cams_event_valid) {
+    RT_HIP(ctx, hipEventSynchronize(ctx->cams_event));   // the previous batch's upload has read the pinned block
+  }
+  std::memcpy(ctx->cams_host, cams12, bytes);
+  RT_HIP(ctx, hipMemcpyAsync(ctx->cams_dev, ctx->cams_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!ctx->cams_event) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->cams_event, hipEventDisableTiming));
+  RT_HIP(ctx, hipEventRecord(ctx->cams_event, ctx->stream));
+  ctx->cams_event_valid = true;
+  *cams_dev = ctx->cams_dev;
+  return 0;
+}
+
 extern "C" int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                                int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
                                int32_t *out_dev) {
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
-  if (ctx->group) return fail(ctx, "rt_render_batch: not on a multi-device context");
   if (nframes < 1 || nframes > 4096) return fail(ctx, "rt_render_batch: 1 .. 4096 frames");
-  const float *cams_dev = nullptr;
-  if (cams12) {
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = sizeof(float) * 12 * static_cast<size_t>(nframes);
-    if (bytes > ctx->cams_bytes) {
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
-      ctx->cams_dev = nullptr;
-      ctx->cams_bytes = 0;
-      RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cams_dev), bytes));
-      ctx->cams_bytes = bytes;
-    }
-    // (stream-ordered: a previous batch still reading the buffer finishes first; the source is copied before return
-    // when it is pageable host memory)
-    RT_HIP(ctx, hipMemcpyAsync(ctx->cams_dev, cams12, bytes, hipMemcpyHostToDevice, ctx->stream));
-    cams_dev = ctx->cams_dev;
+  if (ctx->group) {   // every device renders its rows of ALL the frames in one launch; one gather, one assembly launch
+    if (part != 0 || nparts != 1) return fail(ctx, "a multi-device context renders whole frames: it partitions them itself");
+    if (max_depth < 0) return fail(ctx, "negative max_depth");
+    return rti::group_render(ctx, ps, h, w, max_depth, out_dev, nullptr, nframes, frame_stride, cams12);
   }
+  const float *cams_dev = nullptr;
+  if (int rc = rti::stage_cams(ctx, cams12, nframes, &cams_dev)) return rc;
   return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false, nullptr, nframes, frame_stride, cams_dev);
 }
 
@@ -873,6 +896,22 @@ extern "C" int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, rtk::launch_place_all(stacked_dev, image_dev, static_cast<int>(w), static_cast<int>(h), rows_per_tile, nparts,
                                     static_cast<size_t>(part_stride), ctx->stream));
+  return 0;
+}
+
+extern "C" int rt_place_parts_batch(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t part_stride,
+                                    int32_t nframes, int64_t frame_stride_in, int64_t frame_stride_out, const int32_t *stacked_dev,
+                                    int32_t *images_dev) {
+  if (!ctx || !stacked_dev || !images_dev) return fail(ctx, "null argument");
+  if (rows_per_tile <= 0 || nparts <= 0 || h <= 0 || w <= 0 || nframes < 1) return fail(ctx, "bad row-tile partition");
+  int64_t need = 0;
+  for (int p = 0; p < nparts; ++p) need = std::max<int64_t>(need, rt::part_rows(h, rows_per_tile, p, nparts));
+  if (frame_stride_in < need * w || part_stride < (nframes - 1) * frame_stride_in + need * w || frame_stride_out < h * w)
+    return fail(ctx, "strides smaller than the parts / frames they separate");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, rtk::launch_place_all(stacked_dev, images_dev, static_cast<int>(w), static_cast<int>(h), rows_per_tile, nparts,
+                                    static_cast<size_t>(part_stride), ctx->stream, nframes, static_cast<size_t>(frame_stride_in),
+                                    static_cast<size_t>(frame_stride_out)));
   return 0;
 }
 

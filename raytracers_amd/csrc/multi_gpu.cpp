@@ -18,7 +18,7 @@
 //     for a device list with repeats, which exists to test the fan-out on a one-GPU box).
 // librccl is loaded on demand (dlopen): the single-device library has no RCCL dependency.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl itself is dlopen'ed at the first multi-device frame
 
 #include <algorithm>
 #include <cstring>
@@ -51,6 +51,7 @@ struct rt_group {
   decltype(&ncclRecv) p_recv = nullptr;
   decltype(&ncclGetErrorString) p_errstr = nullptr;
   std::string rccl_note;            // why RCCL is not in use (rt_context_report)
+  bool rccl_failed = false;         // a gather through RCCL failed at run time: peer copies from then on
 };
 
 namespace {
@@ -157,8 +158,9 @@ extern "C" int rt_context_num_devices(const rt_context *ctx) {
 extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
   if (!ctx || !ctx->group || ctx->group->kids.size() < 2) return ctx && ctx->group && ctx->group->gather == 2 ? "rccl" : "none";
   rt_group *g = ctx->group;
-  if (g->gather == 1) return "peer-copy";
-  return load_rccl(g) ? "rccl" : "peer-copy";
+  if (g->gather == 1 || g->rccl_failed || !g->distinct) return "peer-copy";
+  if (!g->rccl_tried) return "rccl (loaded at the first frame; peer copies if that fails)";   // (a getter creates no communicators)
+  return g->comms.empty() ? "peer-copy" : "rccl";
 }
 
 void rti::group_destroy(rt_context *ctx) {
@@ -183,12 +185,28 @@ void rti::group_destroy(rt_context *ctx) {
 
 int rti::group_sync(rt_context *ctx) {
   rt_group *g = ctx->group;
+  // Every stream is drained even when one reports an error, and a device whose launch died gets its ticket counters
+  // re-zeroed (the launch's last wave never did: later frames would draw out-of-range tickets and silently leave that
+  // device's rows stale -- the single-device rt_context_sync does the same).
+  hipError_t first = hipSuccess;
+  std::string where;
   for (rt_context *kid : g->kids) {
-    RT_HIP(ctx, hipSetDevice(kid->device));
-    RT_HIP(ctx, hipStreamSynchronize(kid->stream));
+    hipError_t e = hipSetDevice(kid->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(kid->stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipMemset(kid->queue_dev, 0, sizeof(unsigned) * rtk::kQueueDwords);
+      if (first == hipSuccess) { first = e; where = "device " + std::to_string(kid->device); }
+    }
   }
-  RT_HIP(ctx, hipSetDevice(ctx->device));
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipMemset(ctx->queue_dev, 0, sizeof(unsigned) * rtk::kQueueDwords);
+    if (first == hipSuccess) { first = e; where = "first device"; }
+  }
+  if (first != hipSuccess) return rti::hip_fail(ctx, first, ("stream synchronisation on " + where + " (ticket counters reset)").c_str());
   return 0;
 }
 
@@ -237,28 +255,39 @@ void rti::group_prepared_free(rt_context *ctx, rt_prepared *ps) {
 }
 
 int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,
-                      const float *cam12) {
+                      const float *cam12, int32_t nframes, int64_t frame_stride, const float *cams12) {
   rt_group *g = ctx->group;
   const int n = static_cast<int>(g->kids.size());
   if (ps->replicas.size() != static_cast<size_t>(n)) return fail(ctx, "prepared scene does not belong to this multi-device context");
   if (!out_dev) return fail(ctx, "null output pointer");
   if (h <= 0 || w <= 0 || h * w > (int64_t(1) << 30)) return fail(ctx, "image size out of range");
+  if (nframes < 1 || (nframes > 1 && (frame_stride < h * w || frame_stride * nframes >= (int64_t(1) << 31))))
+    return fail(ctx, "bad batch: nframes >= 1, frame_stride >= h * w, nframes * frame_stride < 2^31");
   constexpr int32_t kRows = 8;
-  const bool want_rccl = g->gather == 2 || (g->gather == 0 && n > 1);
-  const bool rccl = want_rccl && load_rccl(g);
-  if (g->gather == 2 && !rccl) return fail(ctx, "gather=2 (RCCL) requested but unavailable: " + g->rccl_note);
+  const bool want_rccl = !g->rccl_failed && (g->gather == 2 || (g->gather == 0 && n > 1));
+  bool rccl = want_rccl && load_rccl(g);
+  if (g->gather == 2 && !rccl) return fail(ctx, "gather=2 (RCCL) requested but unavailable: " + (g->rccl_failed ? std::string("it failed at run time") : g->rccl_note));
   if (n == 1 && !rccl) {
-    if (rti::enqueue_render(g->kids[0], ps, h, w, max_depth, kRows, 0, 1, out_dev, false, cam12)) return fail(ctx, rt_last_error(g->kids[0]));
+    const float *cams_dev = nullptr;
+    if (nframes > 1 && rti::stage_cams(g->kids[0], cams12, nframes, &cams_dev)) return fail(ctx, rt_last_error(g->kids[0]));
+    if (rti::enqueue_render(g->kids[0], ps, h, w, max_depth, kRows, 0, 1, out_dev, false, cam12, nframes, frame_stride, cams_dev))
+      return fail(ctx, rt_last_error(g->kids[0]));
     // the frame lives on child 0's stream: order the parent's stream (values, frees) behind it
     RT_HIP(ctx, hipEventRecord(g->ev_part[0], g->kids[0]->stream));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ev_part[0], 0));
     return 0;
   }
+  // A device's part buffer: its rows of frame 0, then of frame 1, ... (pad_rows * w elements apart).
   int64_t pad_rows = 0;
   for (int p = 0; p < n; ++p) pad_rows = std::max<int64_t>(pad_rows, rt::part_rows(h, kRows, p, n));
-  const int64_t stride = pad_rows * w;
+  const int64_t fstride = pad_rows * w, stride = fstride * nframes;
+  if (stride >= (int64_t(1) << 31)) return fail(ctx, "batch too large for one gather");
   if (int rc = ensure_buffers(ctx, stride)) return rc;
   const bool all_rccl = rccl && g->gather == 2;   // forced: part 0 travels through RCCL as well (self send/recv)
+  auto part_elems = [&](int i) {                  // what device i has to deliver (0: nothing)
+    const int64_t rows = rt::part_rows(h, kRows, i, n);
+    return rows > 0 ? static_cast<size_t>((nframes - 1) * fstride + rows * w) : size_t(0);
+  };
   for (int i = 0; i < n; ++i) {
     rt_context *kid = g->kids[static_cast<size_t>(i)];
     RT_HIP(ctx, hipSetDevice(kid->device));
@@ -267,11 +296,12 @@ int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t
     const bool direct = i == 0 && !all_rccl;
     int32_t *dst = direct ? g->stacked : g->part[static_cast<size_t>(i)];
     const rt_prepared *kps = i == 0 ? ps : ps->replicas[static_cast<size_t>(i)];
-    if (rti::enqueue_render(kid, kps, h, w, max_depth, kRows, i, n, dst, false, cam12)) return fail(ctx, rt_last_error(kid));
-    const int64_t rows = rt::part_rows(h, kRows, i, n);
-    if (!direct && !rccl && rows > 0)
+    const float *cams_dev = nullptr;
+    if (nframes > 1 && rti::stage_cams(kid, cams12, nframes, &cams_dev)) return fail(ctx, rt_last_error(kid));
+    if (rti::enqueue_render(kid, kps, h, w, max_depth, kRows, i, n, dst, false, cam12, nframes, fstride, cams_dev)) return fail(ctx, rt_last_error(kid));
+    if (!direct && !rccl && part_elems(i) > 0)
       RT_HIP(ctx, hipMemcpyPeerAsync(g->stacked + static_cast<int64_t>(i) * stride, g->devices[0], dst, kid->device,
-                                     sizeof(int32_t) * static_cast<size_t>(rows * w), kid->stream));
+                                     sizeof(int32_t) * part_elems(i), kid->stream));
     RT_HIP(ctx, hipEventRecord(g->ev_part[static_cast<size_t>(i)], kid->stream));
   }
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -280,7 +310,7 @@ int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ev_part[0], 0));
     ncclResult_t r = g->p_gstart();
     for (int i = all_rccl ? 0 : 1; i < n && r == ncclSuccess; ++i) {
-      const size_t count = static_cast<size_t>(rt::part_rows(h, kRows, i, n) * w);
+      const size_t count = part_elems(i);
       if (count == 0) continue;
       // comm[0]'s operations all sit on the parent's stream; a child's send follows its render on its own stream
       hipStream_t sstream = i == 0 ? ctx->stream : g->kids[static_cast<size_t>(i)]->stream;
@@ -289,12 +319,31 @@ int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t
     }
     const ncclResult_t e = g->p_gend();
     if (r == ncclSuccess) r = e;
-    if (r != ncclSuccess) return fail(ctx, std::string("RCCL gather failed: ") + g->p_errstr(r));
-  } else {
-    for (int i = 0; i < n; ++i) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ev_part[static_cast<size_t>(i)], 0));
+    if (r != ncclSuccess) {
+      // The RCCL path has only ever been exercised on one device (the round-end 8-GPU node is the first real run): a
+      // failure must not take the harness down.  This frame's parts still sit in the devices' part buffers: move them
+      // with peer copies, and stay with peer copies.
+      if (g->gather == 2) return fail(ctx, std::string("RCCL gather failed: ") + g->p_errstr(r));
+      g->rccl_failed = true;
+      g->rccl_note = std::string("RCCL gather failed at run time (") + g->p_errstr(r) + "): peer copies since";
+      std::fprintf(stderr, "libray_mi355x: %s\n", g->rccl_note.c_str());
+      rccl = false;
+      for (int i = 1; i < n; ++i) {
+        rt_context *kid = g->kids[static_cast<size_t>(i)];
+        if (part_elems(i) == 0) continue;
+        RT_HIP(ctx, hipSetDevice(kid->device));
+        RT_HIP(ctx, hipMemcpyPeerAsync(g->stacked + static_cast<int64_t>(i) * stride, g->devices[0], g->part[static_cast<size_t>(i)],
+                                       kid->device, sizeof(int32_t) * part_elems(i), kid->stream));
+        RT_HIP(ctx, hipEventRecord(g->ev_part[static_cast<size_t>(i)], kid->stream));
+      }
+      RT_HIP(ctx, hipSetDevice(ctx->device));
+    }
   }
-  RT_HIP(ctx, rtk::launch_place_all(g->stacked, out_dev, static_cast<int>(w), static_cast<int>(h), kRows, n,
-                                    static_cast<size_t>(stride), ctx->stream));
+  if (!rccl)
+    for (int i = 0; i < n; ++i) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ev_part[static_cast<size_t>(i)], 0));
+  // one assembly launch for all frames of the batch
+  RT_HIP(ctx, rtk::launch_place_all(g->stacked, out_dev, static_cast<int>(w), static_cast<int>(h), kRows, n, static_cast<size_t>(stride),
+                                    ctx->stream, nframes, static_cast<size_t>(fstride), static_cast<size_t>(nframes > 1 ? frame_stride : h * w)));
   RT_HIP(ctx, hipEventRecord(g->ev_placed, ctx->stream));
   g->placed_valid = true;
   return 0;

@@ -1121,17 +1121,19 @@ __global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, in
   }
 }
 
-// All parts at once: part p's packed rows start at stacked + p * part_stride (what a gather of the
-// ranks' send buffers to rank 0 delivers; one send buffer may carry several frames).
+// All parts at once, of one frame or of a batch: part p's packed rows of frame f start at
+// stacked + p * part_stride + f * frame_stride_in (what a gather of the ranks' send buffers to rank 0 delivers; a send
+// buffer may carry several frames, or several scenes' frames); frame f's image starts at image + f * frame_stride_out.
 __global__ void place_all_kernel(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                                 size_t part_stride) {
-  const size_t total = (size_t)h * w;
+                                 size_t part_stride, int nframes, size_t frame_stride_in, size_t frame_stride_out) {
+  const size_t per = (size_t)h * w, total = per * (size_t)nframes;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i / w), col = (int)(i - (size_t)row * w);
+    const size_t f = i / per, j = i - f * per;
+    const int row = (int)(j / w), col = (int)(j - (size_t)row * w);
     const int t = row / rows_per_tile;
     const int part = t % nparts, k = t / nparts;
     const int lrow = k * rows_per_tile + (row - t * rows_per_tile);
-    image[i] = stacked[(size_t)part * part_stride + (size_t)lrow * w + col];
+    image[f * frame_stride_out + j] = stacked[(size_t)part * part_stride + f * frame_stride_in + (size_t)lrow * w + col];
   }
 }
 
@@ -1246,12 +1248,12 @@ hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int row
 }
 
 hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                            size_t part_stride, hipStream_t stream) {
-  const size_t total = (size_t)h * w;
+                            size_t part_stride, hipStream_t stream, int nframes, size_t frame_stride_in, size_t frame_stride_out) {
+  const size_t total = (size_t)h * w * (size_t)nframes;
   if (total == 0) return hipSuccess;
   const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(place_all_kernel, dim3(grid), dim3(256), 0, stream, stacked, image, w, h, rows_per_tile, nparts,
-                     part_stride);
+                     part_stride, nframes, frame_stride_in, frame_stride_out);
   return hipGetLastError();
 }
 

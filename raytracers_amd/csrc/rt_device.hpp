@@ -228,7 +228,9 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 
+// (a batch: nframes frames, frame f's parts frame_stride_in elements behind frame f - 1's, its image frame_stride_out behind)
 hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                            size_t part_stride, hipStream_t stream);
+                            size_t part_stride, hipStream_t stream, int nframes = 1, size_t frame_stride_in = 0,
+                            size_t frame_stride_out = 0);
 
 }  // namespace rtk

@@ -68,8 +68,11 @@ struct rt_context {
   // fit): the first prepare_scene then pays no hipMalloc either.
   char *arena = nullptr;
   std::vector<unsigned char> arena_used;   // one flag per granule
-  float *cams_dev = nullptr;   // rt_render_batch: the batch's cameras on the device
+  float *cams_dev = nullptr;   // rt_render_batch: the batch's cameras on the device ...
+  float *cams_host = nullptr;  // ... and the pinned block they are uploaded from (the caller's array is copied into it)
   size_t cams_bytes = 0;
+  hipEvent_t cams_event = nullptr;   // the last upload from cams_host
+  bool cams_event_valid = false;
   rt_group *group = nullptr;   // multi-device context: the devices behind it (multi_gpu.cpp); this context is the first device's
   char *pinned = nullptr;  // host-pinned block the build kernels report through
   char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
@@ -128,8 +131,10 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
                    int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr, int32_t nframes = 1,
                    int64_t frame_stride = 0, const float *cams_dev = nullptr);
 // multi_gpu.cpp
+// (nframes > 1: a batch -- frame f to out_dev + f * frame_stride, through cams12 + 12 f when cams12 is given)
 int group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,
-                 const float *cam12);
+                 const float *cam12, int32_t nframes = 1, int64_t frame_stride = 0, const float *cams12 = nullptr);
+int stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const float **cams_dev);
 int group_prepare(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene);
 void group_prepared_free(rt_context *ctx, rt_prepared *ps);
 int group_sync(rt_context *ctx);

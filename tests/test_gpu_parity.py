@@ -790,7 +790,7 @@ def test_multi_device_context_on_one_gpu(R, scene, h, w):
     cyclic row tiles on three streams, peer-copy gather, assembly) through the single-device entry points."""
     import bench
     mc = R.Context(devices=[0, 0, 0])
-    assert mc.num_devices == 3 and mc.gather_mode == "peer-copy"
+    assert mc.num_devices == 3 and mc.gather_mode == "peer-copy"   # (a getter: no communicators are created for it)
     ps = R.prepare_scene(h, w, mc.scene(scene))
     want, _ = _oracle(scene).render(h, w)
     for rep in range(3):                       # frames chase each other through the shared gather buffers
@@ -814,6 +814,74 @@ def test_multi_device_context_on_one_gpu(R, scene, h, w):
     assert ps.bvh_arrays()["L"].shape == (ps.num_spheres, 7)
     ps.free()
     mc.close()
+
+
+@pytest.mark.parametrize("scene,h,w,nb", [("irreg", 4000, 4000, 6), ("rgbbox", 333, 250, 5)])
+def test_batch_on_a_multi_device_context(R, scene, h, w, nb):
+    """rt_render_batch on a multi-device context (three parts on the one GPU): every device renders its row tiles of ALL the
+    frames in one launch, one gather moves nframes x part per device, ONE assembly launch writes the images.  irreg
+    4000x4000 is the configuration north_star states its scaling target on: six frames, each db269d43.  Then a camera
+    path (a camera per frame) and, with gather=2 on a single device, the same through RCCL send/recv."""
+    import bench
+    import torch
+    mc = R.Context(devices=[0, 0, 0])
+    ps = R.prepare_scene(h, w, mc.scene(scene))
+    buf = torch.empty((nb, h, w), dtype=torch.int32, device="cuda")
+    want = bench.FRAME_CHECKSUM.get((scene, h, w))
+    ref = None if want is not None else _oracle(scene).render(h, w)[0]
+    cks = bench.Checksummer(torch.device("cuda"))
+    for rep in range(2):                          # recording launch, ordered launch
+        buf.fill_(-1)
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, nb, frame_stride=h * w)
+        mc.sync()
+        for f in range(nb):
+            if want is not None:
+                assert cks(buf[f]) == want, (rep, f)
+            else:
+                assert int((buf[f].cpu().numpy() != ref).sum()) == 0, (rep, f)
+    assert int((R.render(h, w, ps) != (ref if ref is not None else buf[0].cpu().numpy())).sum()) == 0   # and a single frame after it
+    ps.free()
+    mc.close()
+    if want is not None:
+        return
+    # a camera per frame, on the multi-device context and through the forced RCCL path of a single device
+    orc = _oracle(scene)
+    cams = np.stack([orc.camera_floats(h + 8 * f, w) for f in range(nb)])
+    for devices, gather in (([0, 0, 0], 0), ([0], 2)):
+        mc = R.Context(devices=devices)
+        mc.set_option("gather", gather)
+        ps = R.prepare_scene(h, w, mc.scene(scene))
+        single = [R.render_image(ps, w, h, cams[f]) for f in range(nb)]
+        buf.fill_(-1)
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, nb, frame_stride=h * w, cams=cams)
+        cams_copy = cams.copy()
+        cams[:] = 0.0                             # the call has copied the cameras: the caller's array is its own again
+        mc.sync()
+        cams[:] = cams_copy
+        for f in range(nb):
+            assert int((buf[f].cpu().numpy() != single[f]).sum()) == 0, (devices, f)
+        ps.free()
+        mc.close()
+
+
+def test_batch_assembly_in_one_launch(R, ctx):
+    """rt_place_parts_batch (what rank 0 runs behind the gather of a batch step) against the per-frame assembly."""
+    import torch
+    h, w, nparts, nb = 77, 53, 3, 4
+    pad = max(R.part_rows(h, p, nparts) for p in range(nparts))
+    fs_in, part_stride = pad * w + 5, nb * (pad * w + 5) + 11
+    rng = np.random.default_rng(3)
+    stacked = torch.from_numpy(rng.integers(-2**31, 2**31 - 1, size=(nparts * part_stride,), dtype=np.int64).astype(np.int32)).cuda()
+    got = torch.full((nb, h, w), -1, dtype=torch.int32, device="cuda")
+    want = torch.full((nb, h, w), -2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    R.place_parts_batch(ctx, h, w, nparts, part_stride, nb, fs_in, stacked.data_ptr(), got.data_ptr())
+    for f in range(nb):
+        R.place_parts(ctx, h, w, nparts, pad, stacked[f * fs_in:].data_ptr(), want[f].data_ptr(), part_stride=part_stride)
+    ctx.sync()
+    assert bool((got == want).all())
 
 
 def test_multi_device_rccl_gather_on_one_gpu(R):

@@ -161,7 +161,7 @@ int main(int argc, char **argv) {
   }
 
   }
-  if (batch > 1 && parts == 1) {
+  if (batch > 1) {   /* (on a multi-device context: every device its rows of all the frames in one launch, one gather) */
     int32_t *bimg = NULL;
     CHECK(ctx, rt_device_alloc(ctx, (void **)&bimg, (int64_t)sizeof(int32_t) * h * w * batch));
     for (int k = 0; k < 2; k++) CHECK(ctx, rt_render_batch(ctx, ps, h, w, depth, 8, 0, 1, batch, NULL, (int64_t)h * w, bimg));
@@ -174,7 +174,16 @@ int main(int argc, char **argv) {
       const double t = (now_s() - tb) / batch;
       if (t < best) best = t;
     }
-    printf("Batch: %d frames in one launch: %.4f ms per frame, %.1f Mray/s\n", batch, best * 1e3, (double)st[0] / best * 1e-6);
+    {
+      /* checksum of the LAST frame of the batch (c = c * 31 + pixel), as for a single frame */
+      int32_t *hb = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
+      uint32_t c = 0;
+      if (hb && rt_copy_to_host(ctx, hb, bimg + (size_t)(batch - 1) * h * w, (int64_t)sizeof(int32_t) * h * w) == 0)
+        for (size_t i = 0; i < (size_t)h * w; i++) c = c * 31u + (uint32_t)hb[i];
+      free(hb);
+      printf("Batch: %d frames in one launch%s: %.4f ms per frame, %.1f Mray/s; last frame's checksum %08x\n", batch,
+             parts > 1 ? " per device" : "", best * 1e3, (double)st[0] / best * 1e-6, c);
+    }
     rt_device_free(ctx, bimg);
   }
 
