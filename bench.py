@@ -90,7 +90,9 @@ WORKLOADS = {
     "big-2000": [("big", 2000, 2000)],
 }
 KERNEL_SOURCES = ["raytracers_amd/csrc/render_kernels.hip", "raytracers_amd/csrc/lane_core.h",
-                  "raytracers_amd/csrc/rt_device.hpp"]
+                  "raytracers_amd/csrc/rt_device.hpp", "raytracers_amd/csrc/treelet.h"]
+# the guide's nominal VALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
+VALU_NOMINAL_PEAK_G = 256 * 4 * 2.4 / 2
 
 
 def log(*a):
@@ -212,7 +214,11 @@ def roofline_block(frames, world, variant, key, steps, elapsed, per_scene, work)
                 peak = float(ip["valu_peak_G"])
                 insts = sum(e["SQ_INSTS_VALU"] for e in ents)
                 ach = insts * steps / elapsed / 1e9
-                rf.update(achieved=ach, peak=peak, frac=ach / peak, insts_per_step=insts,
+                rf.update(achieved=ach, peak=peak, frac=ach / peak, nominal_peak=VALU_NOMINAL_PEAK_G, frac_of_nominal=ach / VALU_NOMINAL_PEAK_G,
+                          insts_per_step=insts,
+                          pmc_source="committed profiles/pmc.json: rocprofv3 --pmc passes of tools/gpu_pmc.sh over the native bench, one "
+                                     "launch at a time, on another box than this run's; tied to the kernel sources by sha256 (checked "
+                                     "above); only the wall time of the timed region is this run's",
                           peak_source="tools/issue_peak.hip (profiles/issue_peak.json): independent v_add/v_mul/v_fma_f32 streams, "
                                       ">= 2 waves per SIMD, all 256 CUs")
                 # the kernel's own mix priced with the measured per-class issue costs
@@ -234,6 +240,34 @@ def roofline_block(frames, world, variant, key, steps, elapsed, per_scene, work)
                                "These bytes are served from LDS (node records, ray table) and L2, not from HBM -- see traffic -- so "
                                "the ratio to the HBM peak is a rate, not a utilisation, and may exceed 1"}
     return rf
+
+
+def serial_roofline(frames, kernel_ms):
+    """the one-frame-at-a-time launches (the reference's protocol) against the same VALU-issue peaks, per scene:
+    PMC counters of a single-frame launch (profiles/pmc.json, key grid_div=0) over this run's kernel times"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue_peak.json")) as f:
+            ip = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if pmc.get("source_sha256") != kernel_source_hash():
+        return {"stale_pmc": True}
+    out = {}
+    for (s, h, w), ms in zip(frames, kernel_ms):
+        e = pmc.get("launches", {}).get(f"{s} {w}x{h}", {}).get("grid_div=0")
+        if not e or "SQ_INSTS_VALU" not in e:
+            continue
+        ach = e["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+        r = {"achieved": ach, "unit": "G wave-instr/s", "frac": ach / float(ip["valu_peak_G"]), "frac_of_nominal": ach / VALU_NOMINAL_PEAK_G,
+             "insts_per_frame": e["SQ_INSTS_VALU"]}
+        if "class_ns" in e:
+            r["valu_pipe_busy"] = e["class_ns"] / (ms * 1e6 * NUM_SIMD)
+        if "hbm_bytes" in e:
+            r["hbm_GBs"] = e["hbm_bytes"] / (ms * 1e-3) / 1e9
+        out[f"{s}_{w}x{h}"] = r
+    return out or None
 
 
 def main():
@@ -446,6 +480,54 @@ def main():
         serial = timed(nser, 0)
         n_verified += verify([serial_lane], "serial region,")
 
+    # The FIRST frames of a view (the reference's `render` is stateless, ray.fut:246; here the tile order, the deep-tile
+    # policy and the solo pixels exist from a view's second frame on) and a camera path (a batch with a camera per frame
+    # has no single view to order tiles by): one GPU only, after the timed regions.
+    cold = None
+    if serial_lane is not None and world == 1 and rank == 0:
+        import raytracers_amd as R
+        first, path = {}, {}
+        for (scene, h, w), pr in zip(frames, serial_lane.prs):
+            ps2 = R.prepare_scene(h, w, pr.scene)              # a fresh prepared scene: no view has been seen
+            img = torch.empty((h, w), dtype=torch.int32, device=device)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
+            for k in range(4):
+                R.render_into(img.data_ptr(), h, w, ps2)
+                ev[k + 1].record()
+            torch.cuda.synchronize()
+            want = FRAME_CHECKSUM.get((scene, h, w))
+            if want is not None and cks(img) != want:
+                raise SystemExit(f"VERIFICATION FAILED: first frames of {scene} {w}x{h}")
+            first[f"{scene}_{w}x{h}"] = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+            # camera path: 20 frames, the prepared camera moved sideways a little more each frame, in one batch launch;
+            # checked against the same cameras rendered one at a time
+            nb = 20
+            cams = np.tile(np.asarray(ps2.camera(), dtype=np.float32).reshape(1, 12), (nb, 1))
+            cams[:, 0] += 0.05 * np.arange(nb, dtype=np.float32)
+            cams[:, 3] += 0.05 * np.arange(nb, dtype=np.float32)
+            buf = torch.empty((nb, h, w), dtype=torch.int32, device=device)
+            for _ in range(2):
+                R.render_batch_into(buf.data_ptr(), h, w, ps2, nb, frame_stride=h * w, cams=cams)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            R.render_batch_into(buf.data_ptr(), h, w, ps2, nb, frame_stride=h * w, cams=cams)
+            b.record()
+            torch.cuda.synchronize()
+            for f in (0, nb - 1):
+                R.render_into(img.data_ptr(), h, w, ps2, cam=cams[f])
+                torch.cuda.synchronize()
+                if cks(img) != cks(buf[f]):
+                    raise SystemExit(f"VERIFICATION FAILED: camera path frame {f} of {scene} {w}x{h} differs from its single render")
+            path[f"{scene}_{w}x{h}"] = a.elapsed_time(b) / nb
+            ps2.free()
+        cold = {"first_frames_ms": first,
+                "first_frames_note": "frames 1..4 of a fresh prepared scene (kernel time, events): frame 1 has no tile order (it records "
+                                     "one), from frame 2 on the view's order / deep-tile policy / solo pixels apply",
+                "camera_path_ms_per_frame": path,
+                "camera_path_note": "20 frames, a camera per frame, ONE rt_render_batch launch (no per-view order); first and last "
+                                    "frame checked against single renders of the same cameras"}
+
     # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
     scale_extra = None
     if world > 1 and not args.no_scale_extra and args.workload == "rgbbox+irreg-1000":
@@ -509,7 +591,9 @@ def main():
             per_scene[f"{scene}_{w}x{h}"] = {
                 "rays": r, "kernel_ms": kern_ms[i], "frames_per_launch": fpl,
                 "Mray_s_kernel": r * fpl / world / (kern_ms[i] * 1e-3) / 1e6, "alg_bytes_per_frame": ba}
-        inflight = sum(kern_ms) * (S if batch else args.steps) / (elapsed * 1e3)
+        # kernel-milliseconds inside the bracket / its wall time (kern_ms: mean duration of a scene's launches; a batch has
+        # S / len(frames) launches per scene, the lanes protocol one per step)
+        inflight = sum(kern_ms) * ((S // len(frames)) if batch else args.steps) / (elapsed * 1e3)
         out = {
             "metric": "Mray/s (primary+secondary) on rgbbox & irreg 1000x1000" if args.workload == "rgbbox+irreg-1000"
                       else f"Mray/s (primary+secondary) on {args.workload}",
@@ -526,7 +610,9 @@ def main():
                        "kernel": {0: "auto (pooled)", 1: "pixel", 2: "persistent", 3: "pooled"}[args.variant],
                        "options": opts_pipe, "protocol": args.protocol if batch or args.protocol == "lanes" else "lanes",
                        "launches_in_flight": S, "frames_per_launch": chunk_sizes,
-                       "partition": f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per step"
+                       "partition": ("one GPU: whole frames, no partition, no gather" if world == 1 and not use_pg else
+                                     f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per launch (all its frames), one "
+                                     "assembly launch per scene")
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
             "per_scene": per_scene,
             "pipeline": {"avg_launches_in_flight": inflight,
@@ -551,6 +637,12 @@ def main():
                 "value": out["serial_value"], "ms_per_step": sdt / nser * 1e3, "kernel_ms": out["serial_ms_per_frame"],
                 "alg_bytes_GBs": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
                                   / (skms[i] * 1e-3) / 1e9 for i, (sc, h, w) in enumerate(frames)}}
+            if world == 1:
+                sr = serial_roofline(frames, skms)
+                if sr:
+                    out["serial"]["roofline"] = sr
+            if cold is not None:
+                out["serial"].update(cold)
             tg = {}
             for i, (sc, h, w) in enumerate(frames):
                 if sc in MI100_RENDER_MS and (h, w) == (1000, 1000) and world == 1:

@@ -233,22 +233,24 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
 // Which tiles of an ordered view are "deep" (their waves do not refill while they trace them) and in how many pieces the
 // deepest ones are handed out.  deep_class >= 0: as configured.  Auto (-1), from the view's class table (tiles with a bounce
 // chain of >= 32 / 16 / 8 scatters: read back once per view, the first time the view is rendered with its order):
-//   * a scene whose tiles with chains of >= 8 bounces would park only a few per cent of the launch's wave time if each of
-//     them kept a wave to itself (irreg: ~700 of 15 625 tiles; weight = sum of chain-length classes <= 2.5 per wave): all
-//     of them are deep, and the deepest waves / 64 tiles go out PIXEL BY PIXEL, one pixel per wave at launch, each traced
-//     by the solo loop (render_kernels.hip: solo_trace) -- the frame's longest chains get a whole wave each from t = 0;
-//     every persistent workgroup is launched (the chains no longer bound the frame, the work does);
-//   * otherwise (rgbbox: 141 tiles of >= 32 bounces, ~3 500 of >= 16): chains of >= 32 bounces are deep, the deepest
-//     waves / 128 tiles go out in quarters (round 2's setting; more held tiles cost more wave time than they save).
+//   * a frame of at most 32768 tiles whose tiles with chains of >= 8 (or >= 16) bounces would park only a few per cent of
+//     the launch's wave time if each of them kept a wave to itself (irreg 1000x1000: ~700 of 15 625 tiles; weight = sum
+//     of chain-length classes <= 2.5 per wave): all of them are deep, and the deepest waves / 64 tiles go out PIXEL BY
+//     PIXEL, one pixel per wave at launch, each traced by the solo loop (render_kernels.hip: solo_trace) -- the frame's
+//     longest chains get a whole wave each from t = 0; every persistent workgroup is launched (the chains no longer bound
+//     the frame, the work does);
+//   * otherwise round 2's setting: chains of >= 32 bounces are deep, the deepest waves / 128 tiles go out in quarters.
+//     rgbbox 1000x1000 (141 tiles of >= 32 bounces, ~3 500 of >= 16): pixel-by-pixel tickets for 64 of them and 77 whole
+//     held tiles measured 5 % slower.  Larger frames are bound by their work, not by their chains: irreg 2000x2000 with
+//     its 56 deepest tiles pixel by pixel +6 %, with chains of >= 16 deep +3.6 %; a rank's quarter of irreg 4000x4000
+//     741 us against 699 (profiles/r03/exp/e24_ab.txt).
 struct DeepPolicy {
   int deep_class, deep_split, cap_log2;
   bool sparse;
 };
 int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves_full, DeepPolicy *dp) {
   *dp = DeepPolicy{ctx->deep_class < 0 ? 3 : ctx->deep_class, ctx->deep_split, ctx->deep_cap_log2, false};
-  // (larger frames are bound by their work, not by their longest chain -- irreg 2000x2000: 0.63 ms against a chain of
-  // ~0.25 ms -- and waves parked on deep tiles only cost them: +3.6 % measured)
-  if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1 || to->ntiles > 32768) return 0;
+  if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1) return 0;
   if (!to->have_classes) {
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RT_HIP(ctx, hipMemcpy(to->classes, to->order + to->ntiles, sizeof to->classes, hipMemcpyDeviceToHost));
@@ -257,6 +259,7 @@ int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves
   if (!ctx->solo || ps->tl_depth != rtk::kTreeletDepth) return 0;
   const int64_t t3 = to->classes[3], t4 = to->classes[4], t5 = to->classes[5];
   const int64_t w4 = 32 * t3 + 16 * (t4 - t3), w5 = w4 + 8 * (t5 - t4), budget = int64_t(5) * waves_full / 2;
+  if (to->ntiles > 32768) return 0;
   if (w5 <= budget) *dp = DeepPolicy{5, 6, 0, true};
   else if (w4 <= budget) *dp = DeepPolicy{4, 6, 0, true};
   return 0;
@@ -680,33 +683,48 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     ps->nodes = reinterpret_cast<float4 *>(b + o_nodes); ps->nodes64 = reinterpret_cast<float4 *>(b + o_nodes64);
     ps->sph = reinterpret_cast<float4 *>(b + o_sph); ps->col = reinterpret_cast<float4 *>(b + o_col);
   }
+  // multi-device context: the other devices build their replicas while this one builds its own (no early return from
+  // here to group_prepare_end)
+  if (ctx->group) rti::group_prepare_begin(ctx, ps.get(), h, w, scene);
   auto put = [&](void *dst, const void *src, size_t bytes) {
     if (!rc && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, "hipMemcpyAsync failed");
   };
   if (ctx->gpu_build) {
     // ---- BVH construction on the GPU (bvh_build.hip): upload the spheres, build in place ----
+    // (a multi-device prepare_scene uploads from one host thread per device: the lock covers the look-up and the
+    // insertion only, not the upload and its stream synchronisation)
     float *scene_dev = nullptr;
     {
       std::lock_guard<std::mutex> lock(scene->mu);
       for (const auto &c : scene->copies)
         if (c.device == ctx->device) scene_dev = c.p;
-      if (!scene_dev) {
-        const size_t sbytes = n * sizeof(rt::Sphere);
-        e = hipMalloc(reinterpret_cast<void **>(&scene_dev), sbytes + 16);
-        if (e == hipSuccess) {
-          if (sbytes + 16 <= kStageBytes) {
-            // small scene: through the pinned staging block and a copy kernel (a pageable hipMemcpy of
-            // a few hundred KB costs milliseconds)
-            std::memcpy(ctx->stage, scene->desc.spheres.data(), sbytes);
-            e = rtk::gpu_copy_from_pinned(scene_dev, ctx->stage, sbytes, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-          } else {
-            e = hipMemcpy(scene_dev, scene->desc.spheres.data(), sbytes, hipMemcpyHostToDevice);
-          }
+    }
+    if (!scene_dev) {
+      const size_t sbytes = n * sizeof(rt::Sphere);
+      float *fresh = nullptr;
+      e = hipMalloc(reinterpret_cast<void **>(&fresh), sbytes + 16);
+      if (e == hipSuccess) {
+        if (sbytes + 16 <= kStageBytes) {
+          // small scene: through the pinned staging block and a copy kernel (a pageable hipMemcpy of
+          // a few hundred KB costs milliseconds)
+          std::memcpy(ctx->stage, scene->desc.spheres.data(), sbytes);
+          e = rtk::gpu_copy_from_pinned(fresh, ctx->stage, sbytes, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        } else {
+          e = hipMemcpy(fresh, scene->desc.spheres.data(), sbytes, hipMemcpyHostToDevice);
         }
-        if (e == hipSuccess) scene->copies.push_back({ctx->device, scene_dev});
-        else if (scene_dev) { (void)hipFree(scene_dev); scene_dev = nullptr; }
       }
+      if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        for (const auto &c : scene->copies)
+          if (c.device == ctx->device) scene_dev = c.p;     // (another context of this device was faster)
+        if (!scene_dev) {
+          scene->copies.push_back({ctx->device, fresh});
+          scene_dev = fresh;
+          fresh = nullptr;
+        }
+      }
+      if (fresh) (void)hipFree(fresh);
     }
     size_t tmp_bytes = rtk::gpu_build_scratch_bytes(static_cast<int>(n));
     char *tmp = nullptr;
@@ -741,15 +759,15 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     // the host staging vectors die at scope exit: drain the copies first
     e = hipStreamSynchronize(ctx->stream);
   }
+  const int grc = ctx->group ? rti::group_prepare_end(ctx, ps.get()) : 0;   // (joins the replica builds whatever happened here)
   if (rc || e != hipSuccess) {
     rt_prepared_free(ctx, ps.release());
     return rc ? rc : hip_fail(ctx, e, "rt_prepare_scene");
   }
-  if (ctx->group)
-    if (int grc = rti::group_prepare(ctx, ps.get(), h, w, scene)) {
-      rt_prepared_free(ctx, ps.release());
-      return grc;
-    }
+  if (grc) {
+    rt_prepared_free(ctx, ps.release());
+    return grc;
+  }
   *out = ps.release();
   return 0;
 }
@@ -1148,8 +1166,9 @@ extern "C" struct futhark_context *futhark_context_new(struct futhark_context_co
   auto ctx = std::make_unique<futhark_context>();
   ctx->logging = cfg ? (cfg->logging | cfg->debugging) : 0;
   // RT_DEVICES lets a harness that never calls set_device (futhark/main.c does not) use several GPUs
+  // (an explicit futhark_context_config_set_device wins over the environment)
   std::vector<int> devs = cfg ? cfg->devices : std::vector<int>();
-  if (const char *env = std::getenv("RT_DEVICES")) devs = parse_device_list(env);
+  if (const char *env = std::getenv("RT_DEVICES"); env && devs.empty() && !(cfg && cfg->device >= 0)) devs = parse_device_list(env);
   const int rc = devs.size() > 1 ? rt_context_create_multi(&ctx->rt, devs.data(), static_cast<int>(devs.size()))
                                  : rt_context_create(&ctx->rt, !devs.empty() ? devs[0] : (cfg ? cfg->device : -1), nullptr, 0);
   if (rc) {

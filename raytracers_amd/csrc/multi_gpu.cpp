@@ -228,19 +228,24 @@ int rti::group_set_option(rt_context *ctx, const char *name, int64_t value) {
   return -1;   // not a group-only option: the caller applies it to the parent as well
 }
 
-// prepare_scene on every device: the parent's own prepared scene (first device) serves child 0,
-// children 1.. build replicas concurrently (one host thread per device: the build ends in a
-// stream synchronise, the reference's harness times this call).
-int rti::group_prepare(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene) {
+// prepare_scene on every device: the parent's own prepared scene (first device) serves child 0, children 1.. build
+// replicas concurrently -- one host thread per device, started BEFORE the parent builds its own (the build ends in a
+// stream synchronise, and the reference's harness times this call).
+void rti::group_prepare_begin(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene) {
   rt_group *g = ctx->group;
   const size_t n = g->kids.size();
   ps->replicas.assign(n, nullptr);
-  std::vector<std::future<int>> jobs;
+  ps->replica_jobs.clear();
   for (size_t i = 1; i < n; ++i)
-    jobs.push_back(std::async(std::launch::async, [=] { return rt_prepare_scene(g->kids[i], &ps->replicas[i], h, w, scene); }));
+    ps->replica_jobs.push_back(std::async(std::launch::async, [=] { return rt_prepare_scene(g->kids[i], &ps->replicas[i], h, w, scene); }));
+}
+int rti::group_prepare_end(rt_context *ctx, rt_prepared *ps) {
+  rt_group *g = ctx->group;
   int rc = 0;
-  for (size_t i = 1; i < n; ++i)
-    if (jobs[i - 1].get() != 0 && !rc) rc = fail(ctx, std::string("device ") + std::to_string(g->devices[i]) + ": " + rt_last_error(g->kids[i]));
+  for (size_t i = 0; i < ps->replica_jobs.size(); ++i)
+    if (ps->replica_jobs[i].get() != 0 && !rc)
+      rc = fail(ctx, std::string("device ") + std::to_string(g->devices[i + 1]) + ": " + rt_last_error(g->kids[i + 1]));
+  ps->replica_jobs.clear();
   (void)hipSetDevice(ctx->device);
   return rc;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -44,8 +45,8 @@ struct rt_context {
   int deep_class = -1;      // pooled family: tiles of cost classes below this (3: chains of >= 32 bounces) get a wave that does not refill (0: off; -1: chosen per view together with deep_split / deep_cap_log2, api.cpp: deep_policy)
   int deep_split = 2;       // ... and is handed out in 2^this pieces to as many waves (a wave with 16 rays walks a chain faster than one with 64)
   int deep_cap_log2 = 5;    // ... while the pieces occupy at most one in 2^this of the launch's waves
-  int xcd_queues = -1;      // pooled family, one frame per launch: 8 ticket counters, one strip of tile columns per XCD (rt_device.hpp); -1: frames of >= 32768 tiles
-  int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers (-1: 2 for batches and frames of >= 32768 tiles, else 0)
+  int xcd_queues = -1;      // pooled family: the tile queue's ticket counters (rt_device.hpp). -1 (auto) = 2: eight counters, one per XCD, taking turns over ONE queue, for every frame and batch; 1: a strip of tile columns per counter (single frames only); 0: one counter
+  int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers. -1 (auto): 0 for a single frame; a batch 2, 1 or 0 by the tiles a wave gets (>= 48, >= 24, fewer)
   int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
   // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
@@ -120,6 +121,7 @@ struct rt_prepared {
   size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
+  std::vector<std::future<int>> replica_jobs;   // ... while they are being built (rt_prepare_scene joins them)
 };
 
 
@@ -135,7 +137,8 @@ int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w,
 int group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,
                  const float *cam12, int32_t nframes = 1, int64_t frame_stride = 0, const float *cams12 = nullptr);
 int stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const float **cams_dev);
-int group_prepare(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene);
+void group_prepare_begin(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w, const rt_scene *scene);   // starts the replicas' builds
+int group_prepare_end(rt_context *ctx, rt_prepared *ps);                                                    // joins them
 void group_prepared_free(rt_context *ctx, rt_prepared *ps);
 int group_sync(rt_context *ctx);
 int group_set_variant(rt_context *ctx, int variant);
