@@ -486,7 +486,7 @@ def main():
     cold = None
     if serial_lane is not None and world == 1 and rank == 0:
         import raytracers_amd as R
-        first, path = {}, {}
+        first, path, path_serial = {}, {}, {}
         for (scene, h, w), pr in zip(frames, serial_lane.prs):
             ps2 = R.prepare_scene(h, w, pr.scene)              # a fresh prepared scene: no view has been seen
             img = torch.empty((h, w), dtype=torch.int32, device=device)
@@ -520,13 +520,30 @@ def main():
                 if cks(img) != cks(buf[f]):
                     raise SystemExit(f"VERIFICATION FAILED: camera path frame {f} of {scene} {w}x{h} differs from its single render")
             path[f"{scene}_{w}x{h}"] = a.elapsed_time(b) / nb
+            # ... and the same path one frame at a time on a fresh prepared scene (the reference's protocol along a path):
+            # every view is new, i.e. every frame is a first frame
+            ps3 = R.prepare_scene(h, w, pr.scene)
+            evp = [torch.cuda.Event(enable_timing=True) for _ in range(nb + 1)]
+            evp[0].record()
+            for f in range(nb):
+                R.render_into(img.data_ptr(), h, w, ps3, cam=cams[f])
+                evp[f + 1].record()
+            torch.cuda.synchronize()
+            if cks(img) != cks(buf[nb - 1]):
+                raise SystemExit(f"VERIFICATION FAILED: camera path (frame by frame) of {scene} {w}x{h}")
+            per = [evp[f].elapsed_time(evp[f + 1]) for f in range(nb)]
+            path_serial[f"{scene}_{w}x{h}"] = {"first": per[0], "mean_of_the_rest": float(np.mean(per[1:]))}
+            ps3.free()
             ps2.free()
         cold = {"first_frames_ms": first,
                 "first_frames_note": "frames 1..4 of a fresh prepared scene (kernel time, events): frame 1 has no tile order (it records "
                                      "one), from frame 2 on the view's order / deep-tile policy / solo pixels apply",
                 "camera_path_ms_per_frame": path,
                 "camera_path_note": "20 frames, a camera per frame, ONE rt_render_batch launch (no per-view order); first and last "
-                                    "frame checked against single renders of the same cameras"}
+                                    "frame checked against single renders of the same cameras",
+                "camera_path_frame_by_frame_ms": path_serial,
+                "camera_path_frame_by_frame_note": "the same 20 cameras one render at a time on a fresh prepared scene: every view is new "
+                                                   "(no tile order, no solo pixels; the frame also records its tile costs)"}
 
     # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
     scale_extra = None

@@ -101,12 +101,14 @@ struct TileOrder {
   int *cost = nullptr;    // [ntiles] record written by the render kernel
   int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
+  uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
   bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
   int classes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct rt_prepared {
   mutable std::vector<TileOrder> orders;
+  mutable uint64_t order_clock = 0;
   int64_t n = 0;
   int64_t h = 0, w = 0;
   rt::Camera cam{};

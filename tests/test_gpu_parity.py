@@ -368,6 +368,34 @@ def test_many_views_of_one_prepared_scene(R, ctx):
             assert int((px != refs[(h, w)]).sum()) == 0, (rnd, h, w)
 
 
+@pytest.mark.parametrize("scene,h,w", [("irreg", 200, 280), ("rgbbox", 333, 250)])
+def test_camera_path_one_frame_at_a_time(R, scene, h, w):
+    """A camera path rendered frame by frame: every view is new (its first frame records its tile costs), and from the ninth
+    view on a new view takes over the least recently used view's buffers as they are (no synchronisation).  Each frame
+    against the same camera rendered without any order."""
+    plain = R.Context()
+    plain.set_variant(3)
+    plain.set_option("adaptive_order", 0)
+    c = R.Context()
+    c.set_variant(3)
+    ps0, ps = R.prepare_scene(h, w, plain.scene(scene)), R.prepare_scene(h, w, c.scene(scene))
+    base = np.asarray(ps.camera(), dtype=np.float32).reshape(12)
+    cams = []
+    for f in range(13):
+        cam = base.copy()
+        cam[0] += 0.4 * f; cam[3] += 0.4 * f          # origin and lower-left corner move together: the camera slides
+        cams.append(cam)
+    want = [R.render_image(ps0, w, h, cam) for cam in cams]
+    assert int((want[0] != _oracle(scene).render(h, w)[0]).sum()) == 0
+    for rnd in range(3):                               # 13 views > 8 kept: borrowed first frames, evictions, revisits
+        for f, cam in enumerate(cams):
+            assert int((R.render_image(ps, w, h, cam) != want[f]).sum()) == 0, (rnd, f)
+        for f in (3, 3, 7):                            # the same view again: its own order, the policy's read-back
+            assert int((R.render_image(ps, w, h, cams[f]) != want[f]).sum()) == 0, (rnd, "again", f)
+    ps.free(); ps0.free()
+    c.close(); plain.close()
+
+
 def test_random_parity_campaign():
     """tools/fuzz_parity.py: a few seconds of random scenes / cameras / sizes / bounce limits, both
     BVH builders and all kernel families against the oracle (a 200 s run covered 29 337 cases)."""
