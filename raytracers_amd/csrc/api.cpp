@@ -421,7 +421,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
       // next frames' ticket -> tile table from this frame's record (also clears the record)
-      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->stream));
+      if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
+      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
       to->valid = true;
       to->have_classes = false;
     }
@@ -504,6 +505,7 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
+  if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   if (ctx->arena) (void)hipFree(ctx->arena);

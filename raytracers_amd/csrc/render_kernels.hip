@@ -1052,58 +1052,131 @@ constexpr int kOrderBins = 64;
 
 __device__ __forceinline__ int order_bin(int v) { return kOrderBins - 1 - min(kOrderBins - 1, max(v, 0)); }   // 0 = longest chains
 
-// One workgroup per shard of the tile queue: it sorts its strip's tiles (row-major within the strip) into the
-// strip's segment of the table and writes the shard's class table behind the table.
-__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(int *cost, int *order, int ntiles, int tiles_x, int nshards) {
-  __shared__ int hist[kOrderBins][kOrderThreads];   // [bin][thread], 32 KB: counts, then exclusive positions
-  __shared__ int bin_base[kOrderBins + 1];
+// Per shard of the tile queue (one, or eight strips) a stable counting sort of the strip's tiles (row-major within the
+// strip) into the strip's segment of the table, by up to kOrderBlocksMax workgroups: every workgroup counts its chunk of
+// the tiles per bin, one workgroup per shard turns the counts into starts (bin-major, then chunk by chunk: stable) and writes
+// the shard's class table, every workgroup places its chunk.  (One workgroup for everything took ~0.09 ms at 1000x1000 and
+// 1.4 ms at 4000x4000 -- behind every frame that records costs, i.e. every first frame of a view.)
+struct OrderChunk {
+  Shard sh;
+  int begin, end;      // this thread's tiles [begin, end) of the shard (thread order = tile order)
+};
+__device__ __forceinline__ OrderChunk order_chunk(int ntiles, int tiles_x, int nshards, int nblocks) {
+  OrderChunk c;
+  const int s = (int)blockIdx.x / nblocks, b = (int)blockIdx.x - s * nblocks;
+  c.sh = shard_of(s, nshards > 1 ? 3 : 0, tiles_x, ntiles / tiles_x);
+  const int n = c.sh.ntiles;
+  const int per_block = (n + nblocks - 1) / nblocks, b0 = min(n, b * per_block), b1 = min(n, b0 + per_block);
+  const int per = (b1 - b0 + kOrderThreads - 1) / kOrderThreads;
+  c.begin = min(b1, b0 + (int)threadIdx.x * per);
+  c.end = min(b1, c.begin + per);
+  return c;
+}
+// hist[bin][thread] = this thread's tiles of that bin (eight independent loads at a time)
+__device__ __forceinline__ void order_count(const OrderChunk &c, const int *cost, int tiles_x, int (*hist)[kOrderThreads]) {
   const int t = threadIdx.x;
-  const Shard sh = shard_of((int)blockIdx.x, nshards > 1 ? 3 : 0, tiles_x, ntiles / tiles_x);
-  const int n = sh.ntiles;
-  int *const table = order + ntiles + kOrderTableDw * (int)blockIdx.x;
-  const int per = (n + kOrderThreads - 1) / kOrderThreads;
-  const int begin = min(n, t * per), end = min(n, begin + per);
   for (int b = 0; b < kOrderBins; ++b) hist[b][t] = 0;
-  for (int i = begin; i < end; ++i) hist[order_bin(cost[shard_tile(sh, i, tiles_x)])][t] += 1;   // a thread touches its own column only
+  for (int i0 = c.begin; i0 < c.end; i0 += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u < c.end ? cost[shard_tile(c.sh, i0 + u, tiles_x)] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < c.end) hist[order_bin(v[u])][t] += 1;   // a thread touches its own column only
+  }
   __syncthreads();
-  // exclusive scan of each bin's row across the threads (thread order = tile order: the sort is stable);
-  // one thread per bin walks its row, the row total lands in bin_base
+}
+// counts[(shard * kOrderBins + bin) * nblocks + block]
+__global__ __launch_bounds__(kOrderThreads) void tile_count_kernel(const int *cost, int ntiles, int tiles_x, int nshards, int nblocks, int *counts) {
+  __shared__ int hist[kOrderBins][kOrderThreads];
+  const OrderChunk c = order_chunk(ntiles, tiles_x, nshards, nblocks);
+  order_count(c, cost, tiles_x, hist);
+  const int t = threadIdx.x;
   if (t < kOrderBins) {
     int acc = 0;
-    for (int k = 0; k < kOrderThreads; ++k) {
-      const int c = hist[t][k];
-      hist[t][k] = acc;
+    for (int k = 0; k < kOrderThreads; ++k) acc += hist[t][k];
+    const int s = (int)blockIdx.x / nblocks, b = (int)blockIdx.x - s * nblocks;
+    counts[(s * kOrderBins + t) * nblocks + b] = acc;
+  }
+}
+// one workgroup per shard: counts -> starts within the shard's segment; the shard's class table
+__global__ __launch_bounds__(kOrderThreads) void tile_scan_kernel(int *counts, int *order, int ntiles, int nblocks) {
+  __shared__ int bin_tot[kOrderBins + 1];
+  const int t = threadIdx.x, s = (int)blockIdx.x;
+  int *const cs = counts + s * kOrderBins * nblocks;
+  if (t < kOrderBins) {      // exclusive scan of bin t's counts over the chunks
+    int acc = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      const int c = cs[t * nblocks + b];
+      cs[t * nblocks + b] = acc;
       acc += c;
     }
-    bin_base[t] = acc;
+    bin_tot[t] = acc;
   }
   __syncthreads();
   if (t == 0) {
     int acc = 0;
     for (int b = 0; b < kOrderBins; ++b) {
-      const int c = bin_base[b];
-      bin_base[b] = acc;
+      const int c = bin_tot[b];
+      bin_tot[b] = acc;
       acc += c;
     }
-    bin_base[kOrderBins] = acc;
+    bin_tot[kOrderBins] = acc;
     // first ticket of each coarse class (class c = chains of 2^(7-c) .. 2^(8-c) - 1 bounces): the render kernel
     // treats the tickets below order[ntiles + deep_class] as deep tiles, a batch hands tickets out class-major
-    for (int c = 0; c < kOrderClasses; ++c) table[c] = bin_base[order_bin((1 << (kOrderClasses - c)) - 1)];
+    int *const table = order + ntiles + kOrderTableDw * s;
+    for (int c = 0; c < kOrderClasses; ++c) table[c] = bin_tot[order_bin((1 << (kOrderClasses - c)) - 1)];
     table[kOrderClasses] = acc;
   }
   __syncthreads();
-  for (int i = begin; i < end; ++i) {
-    const int tile = shard_tile(sh, i, tiles_x);
-    const int b = order_bin(cost[tile]);
-    order[sh.seg + bin_base[b] + hist[b][t]] = tile;
-    hist[b][t] += 1;
-    cost[tile] = 0;
+  if (t < kOrderBins)
+    for (int b = 0; b < nblocks; ++b) cs[t * nblocks + b] += bin_tot[t];
+}
+__global__ __launch_bounds__(kOrderThreads) void tile_place_kernel(int *cost, int *order, int ntiles, int tiles_x, int nshards, int nblocks,
+                                                                  const int *starts) {
+  __shared__ int hist[kOrderBins][kOrderThreads];   // [bin][thread], 32 KB: counts, then exclusive positions
+  const OrderChunk c = order_chunk(ntiles, tiles_x, nshards, nblocks);
+  order_count(c, cost, tiles_x, hist);
+  const int t = threadIdx.x;
+  const int s = (int)blockIdx.x / nblocks, b = (int)blockIdx.x - s * nblocks;
+  // exclusive scan of each bin's row across the threads (thread order = tile order: the sort is stable), from the chunk's start
+  if (t < kOrderBins) {
+    int acc = starts[(s * kOrderBins + t) * nblocks + b];
+    for (int k = 0; k < kOrderThreads; ++k) {
+      const int n = hist[t][k];
+      hist[t][k] = acc;
+      acc += n;
+    }
+  }
+  __syncthreads();
+  for (int i0 = c.begin; i0 < c.end; i0 += 8) {
+    int tile[8], v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      tile[u] = shard_tile(c.sh, i0 + u < c.end ? i0 + u : c.begin, tiles_x);
+      v[u] = cost[tile[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < c.end) {
+        const int bin = order_bin(v[u]);
+        order[c.sh.seg + hist[bin][t]] = tile[u];
+        hist[bin][t] += 1;
+        cost[tile[u]] = 0;
+      }
   }
 }
 
-hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, hipStream_t stream) {
+// `scratch`: kOrderScratchInts ints of device memory (the chunks' counts)
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, int *scratch, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
-  hipLaunchKernelGGL(tile_order_kernel, dim3(nshards), dim3(kOrderThreads), 0, stream, cost, order, ntiles, tiles_x, nshards);
+  const int per_shard = (ntiles + nshards - 1) / nshards;
+  int nblocks = (per_shard + 2047) / 2048;
+  nblocks = nblocks < 1 ? 1 : (nblocks > kOrderBlocksMax ? kOrderBlocksMax : nblocks);
+  hipLaunchKernelGGL(tile_count_kernel, dim3(nshards * nblocks), dim3(kOrderThreads), 0, stream, cost, ntiles, tiles_x, nshards, nblocks, scratch);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(nshards), dim3(kOrderThreads), 0, stream, scratch, order, ntiles, nblocks);
+  hipLaunchKernelGGL(tile_place_kernel, dim3(nshards * nblocks), dim3(kOrderThreads), 0, stream, cost, order, ntiles, tiles_x, nshards, nblocks,
+                     scratch);
   return hipGetLastError();
 }
 
@@ -1234,7 +1307,9 @@ void warm_render_kernels() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false>);
-  (void)hipFuncGetAttributes(&a, (const void *)tile_order_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)tile_count_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)tile_scan_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)tile_place_kernel);
 }
 
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,

@@ -224,7 +224,9 @@ size_t gpu_build_pinned_bytes();         // host-pinned block the build kernels 
 hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, char *scratch, char *pinned, hipStream_t stream,
                          int *height_out, float root_lo[3], float root_hi[3]);
 
-hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, hipStream_t stream);
+constexpr int kOrderBlocksMax = 64;                                   // workgroups per shard of the tile-order sort
+constexpr int kOrderScratchInts = kMaxShards * 64 * kOrderBlocksMax;   // its scratch: [shard][bin][workgroup] counts
+hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, int *scratch, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

@@ -51,6 +51,7 @@ struct rt_context {
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
   // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
   unsigned *queue_dev = nullptr;
+  int *order_scratch = nullptr;   // the tile-order sort's chunk counts (rtk::kOrderScratchInts), allocated with the first record
   unsigned long long *stats_dev = nullptr;
   // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
   struct UvTable {

@@ -932,15 +932,43 @@ def test_multi_device_real_devices(R):
     n = int(lib.rt_device_count())
     if n < 2:
         pytest.skip("one GPU")
+    import bench
+    import torch
     mc = R.Context(devices=list(range(n)))
-    assert mc.gather_mode == "rccl"
+    assert mc.gather_mode.startswith("rccl")           # (loaded at the first frame; falls back to peer copies if RCCL fails)
     for scene, h, w in (("irreg", 4000, 4000), ("rgbbox", 1000, 1000)):
         ps = R.prepare_scene(h, w, mc.scene(scene))
-        img = R.render(h, w, ps)
-        import bench
-        assert O.checksum(img) == bench.FRAME_CHECKSUM[(scene, h, w)]
+        for rep in range(3):
+            assert O.checksum(R.render(h, w, ps)) == bench.FRAME_CHECKSUM[(scene, h, w)], rep
+        # ... and a batch: every device its rows of all six frames in one launch, one gather, one assembly launch
+        buf = torch.full((6, h, w), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 6, frame_stride=h * w)
+        mc.sync()
+        cks = bench.Checksummer(torch.device("cuda:0"))
+        assert all(cks(buf[f]) == bench.FRAME_CHECKSUM[(scene, h, w)] for f in range(6))
         ps.free()
+    assert mc.gather_mode in ("rccl", "peer-copy")     # which of the two carried the frames (the report says why)
     mc.close()
+
+
+def test_bench_line_on_two_real_gpus():
+    """The driver's N = 2 command as it is (one rank per GPU, backend nccl = RCCL over xGMI): sharded steps verified against
+    the oracle's checksums, one gather per launch, one assembly launch per scene (skipped on a one-GPU box)."""
+    import json
+    import sys
+    from raytracers_amd._lib import lib
+    if int(lib.rt_device_count()) < 2:
+        pytest.skip("one GPU")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["value"] > 0
+    assert d["irreg_4000"]["verified"] is True
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0-0"])
