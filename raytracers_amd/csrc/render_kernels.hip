@@ -1197,16 +1197,26 @@ __global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, in
 // All parts at once, of one frame or of a batch: part p's packed rows of frame f start at
 // stacked + p * part_stride + f * frame_stride_in (what a gather of the ranks' send buffers to rank 0 delivers; a send
 // buffer may carry several frames, or several scenes' frames); frame f's image starts at image + f * frame_stride_out.
-__global__ void place_all_kernel(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
-                                 size_t part_stride, int nframes, size_t frame_stride_in, size_t frame_stride_out) {
-  const size_t per = (size_t)h * w, total = per * (size_t)nframes;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t f = i / per, j = i - f * per;
-    const int row = (int)(j / w), col = (int)(j - (size_t)row * w);
+// One workgroup per image row at a time: where the row comes from is scalar arithmetic once per row, the copy itself is
+// 16-byte loads and stores when the row length and the strides allow it (an element-wise version with four integer
+// divisions per pixel moved 2.7 TB/s: 49 us per 4000x4000 frame on rank 0's critical path behind every gather).
+__global__ __launch_bounds__(256) void place_all_kernel(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
+                                                        size_t part_stride, int nframes, size_t frame_stride_in, size_t frame_stride_out, int vec) {
+  const size_t nrows = (size_t)h * (size_t)nframes;
+  for (size_t rid = blockIdx.x; rid < nrows; rid += gridDim.x) {
+    const int f = (int)(rid / (size_t)h), row = (int)(rid - (size_t)f * h);
     const int t = row / rows_per_tile;
     const int part = t % nparts, k = t / nparts;
     const int lrow = k * rows_per_tile + (row - t * rows_per_tile);
-    image[f * frame_stride_out + j] = stacked[(size_t)part * part_stride + f * frame_stride_in + (size_t)lrow * w + col];
+    const int32_t *const src = stacked + (size_t)part * part_stride + (size_t)f * frame_stride_in + (size_t)lrow * w;
+    int32_t *const dst = image + (size_t)f * frame_stride_out + (size_t)row * w;
+    if (vec) {
+      const int4 *const s4 = reinterpret_cast<const int4 *>(src);
+      int4 *const d4 = reinterpret_cast<int4 *>(dst);
+      for (int i = threadIdx.x; i < (w >> 2); i += 256) d4[i] = s4[i];
+    } else {
+      for (int i = threadIdx.x; i < w; i += 256) dst[i] = src[i];
+    }
   }
 }
 
@@ -1324,11 +1334,13 @@ hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int row
 
 hipError_t launch_place_all(const int32_t *stacked, int32_t *image, int w, int h, int rows_per_tile, int nparts,
                             size_t part_stride, hipStream_t stream, int nframes, size_t frame_stride_in, size_t frame_stride_out) {
-  const size_t total = (size_t)h * w * (size_t)nframes;
-  if (total == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  const size_t nrows = (size_t)h * (size_t)nframes;
+  if (nrows == 0 || w <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)(nrows < 16384 ? nrows : 16384);
+  const bool vec = w % 4 == 0 && part_stride % 4 == 0 && frame_stride_in % 4 == 0 && frame_stride_out % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(stacked) | reinterpret_cast<uintptr_t>(image)) % 16 == 0;
   hipLaunchKernelGGL(place_all_kernel, dim3(grid), dim3(256), 0, stream, stacked, image, w, h, rows_per_tile, nparts,
-                     part_stride, nframes, frame_stride_in, frame_stride_out);
+                     part_stride, nframes, frame_stride_in, frame_stride_out, vec ? 1 : 0);
   return hipGetLastError();
 }
 
