@@ -50,6 +50,10 @@ build/issue_peak: tools/issue_peak.hip
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-inline-asm -o $@ $<
 
+build/hip_touch: tools/hip_touch.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
+
 # the pooled kernel's tile-queue protocol (rt_device.hpp) played on the CPU; in the CPU test suite
 build/queue_check: tools/queue_check.cpp $(CSRC)/rt_device.hpp $(CSRC)/lane_core.h
 	@mkdir -p build
@@ -60,7 +64,7 @@ build/treelet_probe: tools/treelet_probe.cpp $(CSRC)/lane_core.h $(CSRC)/treelet
 	@mkdir -p build
 	$(CXX) $(HOSTFLAGS) -I$(CSRC) -o $@ tools/treelet_probe.cpp $(OBJ)/host_build.o
 
-tools: build/rtbench build/issue_peak build/queue_check build/treelet_probe
+tools: build/rtbench build/issue_peak build/queue_check build/treelet_probe build/hip_touch
 
 oracle:
 	$(MAKE) -s -C oracle

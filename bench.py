@@ -44,6 +44,7 @@ serves those bytes, and against the 8 TB/s HBM peak for reference) together with
 """
 import argparse
 import hashlib
+import contextlib
 import json
 import os
 import sys
@@ -292,6 +293,8 @@ def main():
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
     ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
+    ap.add_argument("--idle-before-ms", type=float, default=0.0,
+                    help="experiment: idle the GPU this long between the warm-up steps and the timed bracket (DESIGN.md 6, first-process effect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-extra", action="store_true", help="N > 1: skip the irreg 4000x4000 sub-record")
     args = ap.parse_args()
@@ -404,12 +407,15 @@ def main():
             torch.cuda.synchronize()
 
     def poison(which):
-        """overwrite the framebuffers so that only the timed launches can make them right"""
+        """overwrite the framebuffers so that only the timed launches can make them right -- on the stream the lane's launches
+        go to, i.e. ordered behind its warm-up launches without a host-side wait"""
         for ln in which:
-            for img in (ln.step.images or []):
-                img.fill_(0x5a5a5a5a)
-            if not ln.step.direct:
-                ln.step.send.fill_(0x5a5a5a5a)
+            st = next((s_ for s_, l_ in zip(streams, lanes) if l_ is ln), None)
+            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                for img in (ln.step.images or []):
+                    img.fill_(0x5a5a5a5a)
+                if not ln.step.direct:
+                    ln.step.send.fill_(0x5a5a5a5a)
 
     cks = Checksummer(device)
 
@@ -464,17 +470,25 @@ def main():
     # untimed warm-up steps, then exactly K timed steps.
     for k in range(2 * S):
         step(k)
+    # Everything the host does for the FIRST time goes here, ahead of the warm-up steps, not between them and the bracket:
+    # the first fill_ of a process loads torch's code object for it, and as the first GPU process of a fresh box (cold page
+    # cache: what the driver's run is) that takes long enough for the idle GPU to drop its clock -- the timed launches then
+    # ran their unchanged cycle counts at 2.2 instead of 2.38 GHz (profiles/r03/first_process_pmc.txt).
+    poison(lanes)
+    torch.cuda.Event(enable_timing=True).record()
+    torch.cuda.synchronize()
     for k in range(2 * S if (batch and args.warmup > 0) else args.warmup):   # (batch: two more passes of all K >= W steps)
         step(k)
-    torch.cuda.synchronize()
-    poison(lanes)
+    poison(lanes)                       # stream-ordered behind the warm-up launches; the bracket's fence waits for it
+    if args.idle_before_ms > 0:         # the experiment behind the comment above: let the GPU idle ahead of the bracket
+        torch.cuda.synchronize()
+        time.sleep(args.idle_before_ms * 1e-3)
     elapsed, kern_ms = timed(args.steps, S)
     n_verified = verify(lanes, "timed region,")
     serial = None
     if serial_lane is not None:
         for k in range(3):
             step(k, None, 0)
-        torch.cuda.synchronize()
         poison([serial_lane])
         nser = max(10, args.steps // 2)
         serial = timed(nser, 0)
