@@ -257,16 +257,17 @@ struct Op {
 };
 
 int main(int argc, char **argv) {
-  int iters = 2000;
+  int iters = 2000, warm = 1;
   const char *only = nullptr;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "-i") && i + 1 < argc) iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-k") && i + 1 < argc) only = argv[++i];
+    else if (!strcmp(argv[i], "-W") && i + 1 < argc) warm = atoi(argv[++i]);   // untimed launches ahead of the timed one
   }
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  printf("# device %s, %d CUs, clockRate %d kHz; iters %d\n", prop.name, cus, prop.clockRate, iters);
+  printf("# device %s, %d CUs, clockRate %d kHz; iters %d, %d warm-up launches\n", prop.name, cus, prop.clockRate, iters, warm);
   printf("# ns/inst/SIMD = kernel wall time (events) / (instructions per wave x waves per SIMD); an LDS instruction's share of its CU's LDS pipeline is a quarter of it\n");
   printf("# memtime/inst = mean s_memtime ticks per wave / (instructions per wave x waves per SIMD); wave-busy = mean s_memrealtime span of a wave's loop / kernel wall time\n");
   printf("# chip G inst/s = CUs x 4 SIMDs / (ns/inst/SIMD)\n");
@@ -321,7 +322,7 @@ int main(int argc, char **argv) {
       const int blocks = (w <= 4 ? 1 : 2) * cus;
       const int it = op.lds ? iters / 4 + 1 : iters;
       Args a{cyc, sink, it, op.pattern};
-      hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 65536, 0, a);   // warm-up
+      for (int k = 0; k < warm; ++k) hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 65536, 0, a);   // warm-up
       CHECK(hipEventRecord(e0));
       hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 65536, 0, a);
       CHECK(hipEventRecord(e1));
