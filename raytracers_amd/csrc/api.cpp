@@ -993,7 +993,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   if (rc || pl.variant != RT_VARIANT_POOLED || (pl.waves != 16 && pl.waves != 8)) rc = make_plan(ctx, ps, &pl, ((w + 7) / 8) * ((h + 7) / 8), 8);
   ctx->variant = saved;
   if (rc) return rc;
-  const int nw = pl.grid * pl.waves;
+  int nw = std::max(pl.grid, pl.grid_full) * pl.waves;   // (the buffers: the view's policy may ask for every workgroup, below)
   if (nw > max_waves) return fail(ctx, "trace buffer too small");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30)) return fail(ctx, "image size out of range");
   int32_t *tmp = nullptr;
@@ -1053,7 +1053,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
         p.deep_class = dp.deep_class;
         p.deep_split = dp.deep_split;
         p.deep_cap_log2 = dp.cap_log2;
+        if (dp.sparse && ctx->grid_div == 0) pl.grid = pl.grid_full;   // as enqueue_render launches this view
       }
+    nw = pl.grid * pl.waves;
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * rtk::kTraceWords * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
