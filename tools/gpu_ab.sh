@@ -14,6 +14,6 @@ export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-20}
 while IFS='|' read -r lib s n mode rest; do
   [ -z "$lib" ] && continue
   o=""; for kv in $rest; do o="$o -o $kv"; done
-  res=$( ( [ "$lib" != new ] && export LD_LIBRARY_PATH=$PWD/build/lib_$lib:$LD_LIBRARY_PATH; timeout 120 ./build/rtbench -s $s -n $n -m $n $mode $o 2>&1 ) | grep -E "HIP-event|Checksum|Batch|Overlapped|failed|unknown|no HIP" | tr '\n' ' ')
+  res=$( ( [ "$lib" != new ] && export LD_LIBRARY_PATH=$PWD/build/lib_$lib:$LD_LIBRARY_PATH; timeout ${AB_TIMEOUT:-120} ./build/rtbench -s $s -n $n -m $n $mode $o 2>&1 ) | grep -E "HIP-event|Checksum|Batch|Overlapped|failed|unknown|no HIP" | tr '\n' ' ')
   echo "$lib $s $n $mode [$rest] : $res"
 done | tee "$OUT"
