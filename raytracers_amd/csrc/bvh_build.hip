@@ -479,6 +479,9 @@ __global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int 
 // the traversal numbering live in LDS (2 x 4n bytes <= 128 KB); boxes stay in global memory (L2).
 constexpr int kSmallNT = 1024;
 constexpr int kSmallMax = 16384;   // digit totals fit the packed 16-bit counters
+// ... and it is USED up to kSmallUse spheres: one workgroup takes 0.089 ms + 28 ns per sphere beyond 1000, the chain of launches
+// below 0.25 ms + 0.7 ns per sphere (profiles/r03/exp/bvh_sizes_before.txt: 0.527 ms at n = 16 384 against 0.254 at 16 641)
+constexpr int kSmallUse = 6144;
 constexpr int kSmallE = 17;        // consecutive elements a thread owns in a sort pass (odd: LDS stride)
 
 struct SmallArgs {
@@ -881,7 +884,7 @@ ScratchLayout scratch_layout(int n) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
   l.centres = carve(sizeof(float) * 3 * (size_t)n);
-  if (n <= kSmallMax) {
+  if (n <= kSmallUse) {
     l.box4 = carve(sizeof(float4) * 4 * ni);
     l.v0 = carve(sizeof(int) * ni);
     l.trav = carve(sizeof(int) * ni);
@@ -944,7 +947,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   int *result = (int *)pinned;
   const float *root = (const float *)(result + 4);
 
-  if (n <= kSmallMax) {
+  if (n <= kSmallUse) {
     // the whole build in one workgroup / one launch
     SmallArgs a{sph7_dev, n, (int)log2f((float)n) + 2, o, centres, (float4 *)(scratch + l.box4),
                 (int *)(scratch + l.v0), (int *)(scratch + l.trav), result};

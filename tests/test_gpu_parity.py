@@ -48,8 +48,9 @@ def _scene(ctx, scene):
 @pytest.mark.parametrize("gpu_build", [1, 0])
 @pytest.mark.parametrize("scene", ["rgbbox", "irreg", "floor:37:222", "floor:2:12", "floor:300:1800",
                                    # the builder's size boundaries: 1 / 3 elements per thread in the one-workgroup
-                                   # sort, its largest scene (16384) and the smallest multi-kernel one
-                                   "floor:32:192", "floor:33:198", "floor:128:768", "floor:129:774"])
+                                   # sort, the largest scene it is used for (6084 <= 6144 spheres) and the smallest
+                                   # multi-kernel one (6241), and either side of the one-workgroup kernel's capacity (16384)
+                                   "floor:32:192", "floor:33:198", "floor:78:468", "floor:79:474", "floor:128:768", "floor:129:774"])
 def test_bvh_arrays_bit_exact(R, ctx, scene, gpu_build):
     """prepare_scene's {L, I} (bvh.fut:28) from the GPU builder (bvh_build.hip) and from the
     host builder, both against the oracle: spheres, child pointers, parents and boxes bit-exact."""
