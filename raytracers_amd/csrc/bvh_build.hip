@@ -214,9 +214,38 @@ __global__ __launch_bounds__(kBT) void scan_small_kernel(unsigned *data, int m) 
   }
 }
 
+// RAW: block_offsets holds the blocks' digit COUNTS as sort_count_kernel wrote them (no scan launch in between); every block
+// derives its own 16 offsets from them -- digit-major exclusive prefix: the elements of smaller digits in all blocks, then
+// those of the same digit in the blocks before this one.  For scenes of up to kSortRawBlocks blocks (131 072 elements), where
+// a dispatch (~3.5 us of dependent-launch gap) costs more than 16 x nblocks loads per block.
+constexpr int kSortRawBlocks = 128;
+template <bool RAW>
 __global__ __launch_bounds__(kBT) void sort_scatter_kernel(const unsigned *keys_in, const int *vals_in, int n, int shift,
                                                            const unsigned *block_offsets, int nblocks, unsigned *keys_out,
                                                            int *vals_out) {
+  __shared__ unsigned s_all[kSortDigits][kBT / kSortDigits], s_before[kSortDigits][kBT / kSortDigits], s_off[kSortDigits];
+  if (RAW) {
+    const int d = threadIdx.x & (kSortDigits - 1), c = threadIdx.x / kSortDigits;   // digit, chunk of the block list
+    unsigned all = 0, before = 0;
+    for (int b = c; b < nblocks; b += kBT / kSortDigits) {
+      const unsigned v = block_offsets[d * nblocks + b];
+      all += v;
+      before += b < (int)blockIdx.x ? v : 0u;
+    }
+    s_all[d][c] = all;
+    s_before[d][c] = before;
+    __syncthreads();
+    if (threadIdx.x < kSortDigits) {
+      unsigned smaller = 0, mine = 0;
+      for (int dd = 0; dd < kSortDigits; ++dd)
+        for (int cc = 0; cc < kBT / kSortDigits; ++cc) {
+          smaller += dd < (int)threadIdx.x ? s_all[dd][cc] : 0u;
+          mine += dd == (int)threadIdx.x ? s_before[dd][cc] : 0u;
+        }
+      s_off[threadIdx.x] = smaller + mine;
+    }
+    __syncthreads();
+  }
   const int base = (blockIdx.x * kBT + threadIdx.x) * kSortE;
   unsigned k[kSortE];
   int v[kSortE];
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(kBT) void sort_scatter_kernel(const unsigned *keys_
   for (int e = 0; e < kSortE; ++e) {
     if (base + e < n) {
       const unsigned d = (k[e] >> shift) & (kSortDigits - 1);
-      const unsigned pos = block_offsets[d * nblocks + blockIdx.x] + digit_get(rank, d);
+      const unsigned pos = (RAW ? s_off[d] : block_offsets[d * nblocks + blockIdx.x]) + digit_get(rank, d);
       keys_out[pos] = k[e];
       vals_out[pos] = v[e];
       digit_add(rank, d);
@@ -293,6 +322,19 @@ __device__ __forceinline__ void radix_tree_node(int i, const unsigned *L, int n,
     parent[gamma + 1] = i;
   }
 }
+// the four fills ahead of the tree and the sweeps in one dispatch: parent = -1, both "previous" box buffers = 0, fin = 0x7f7f7f7f
+__global__ __launch_bounds__(kBT) void build_fills_kernel(int *parent, float *pmin, float *pmax, int *fin, int ni) {
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i >= ni) return;
+  parent[i] = -1;
+  fin[i] = 0x7f7f7f7f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    pmin[3 * i + k] = 0.0f;
+    pmax[3 * i + k] = 0.0f;
+  }
+}
+
 __global__ __launch_bounds__(kBT) void radix_tree_kernel(const unsigned *L, int n, int *left, int *right, int *parent) {
   const int i = blockIdx.x * kBT + threadIdx.x;
   if (i < n - 1) radix_tree_node(i, L, n, left, right, parent);
@@ -858,8 +900,12 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
                      hipStream_t st) {
   const int nblocks = cdiv(n, kBT * kSortE);
   hipLaunchKernelGGL(sort_count_kernel, dim3(nblocks), dim3(kBT), 0, st, kin, n, shift, counts, nblocks);
-  hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, kSortDigits * nblocks);
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(kBT), 0, st, kin, vin, n, shift, counts, nblocks, kout, vout);
+  if (nblocks <= kSortRawBlocks) {
+    hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(kBT), 0, st, kin, vin, n, shift, counts, nblocks, kout, vout);
+  } else {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, kSortDigits * nblocks);
+    hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nblocks), dim3(kBT), 0, st, kin, vin, n, shift, counts, nblocks, kout, vout);
+  }
   return hipGetLastError();
 }
 
@@ -985,18 +1031,14 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
     cur ^= 1;
   }
   hipLaunchKernelGGL(gather_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, sph7_dev, vals[cur], n, o.L7);
-  // 3. radix tree over the sorted keys
-  BVH_HIP(hipMemsetAsync(o.parent, 0xFF, sizeof(int) * (size_t)ni, st));   // -1
-  hipLaunchKernelGGL(radix_tree_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], n, o.left, o.right, o.parent);
-  // 4. AABB propagation: exactly floor(log2 n) + 2 sweeps from all-zero boxes
+  // 3. radix tree over the sorted keys; 4. AABB propagation: exactly floor(log2 n) + 2 sweeps from all-zero boxes
   const int sweeps = (int)log2f((float)n) + 2;
   float *pmin = bufmin, *pmax = bufmax, *cmin = o.bmin, *cmax = o.bmax;
   if (sweeps % 2 == 0) {   // the last sweep must land in o.bmin / o.bmax
     pmin = o.bmin; pmax = o.bmax; cmin = bufmin; cmax = bufmax;
   }
-  BVH_HIP(hipMemsetAsync(pmin, 0, sizeof(float) * 3 * (size_t)ni, st));
-  BVH_HIP(hipMemsetAsync(pmax, 0, sizeof(float) * 3 * (size_t)ni, st));
-  BVH_HIP(hipMemsetAsync(depth, 0x7F, sizeof(int) * (size_t)ni, st));   // fin[] = 0x7f7f7f7f (borrowed: depth[] is set later)
+  hipLaunchKernelGGL(build_fills_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, pmin, pmax, depth, ni);   // (fin[] borrows depth[], which is set later)
+  hipLaunchKernelGGL(radix_tree_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], n, o.left, o.right, o.parent);
   for (int s = 0; s < sweeps; ++s) {
     hipLaunchKernelGGL(aabb_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax,
                        depth, s);
