@@ -334,8 +334,9 @@ def main():
         # K steps in C launches per scene (default 1: every launch ends with the frame's longest bounce chain, ~0.5 ms that
         # a rank with an eighth of the rows cannot afford twice), the scenes' launches on separate streams (they overlap
         # where one's tail leaves CUs idle; each has its own gather).  One-GPU stand-in for a rank's share of K = 20 steps
-        # (tools/rank_share_probe.py, us per step, slowest part): W = 1 / 2 / 4 / 8 = 377 / 197 / 114 / 95 with full-size
-        # launches, 76 at W = 8 with half-size ones (two scenes side by side instead of one after the other).
+        # (tools/rank_share_probe.py, us per step, slowest part; profiles/r03/rank_share_probe.txt): W = 1 / 2 / 4 / 8 =
+        # 370 / 191 / 106 / 62 with full-size launches, 69 at W = 8 with half-size ones (round 2, when a rank's eighth was
+        # bound by its bounce chains, it was the other way round -- 95 against 76 -- and W >= 8 launched half-size).
         C = max(1, min(args.chunks or 1, args.steps))
         chunk_sizes = [args.steps // C + (1 if i < args.steps % C else 0) for i in range(C) for _ in frames]
         # launch order: the LAST scene first.  Persistent workgroups of two launches do not share a CU (each fills its LDS), so
@@ -344,8 +345,6 @@ def main():
         lane_frames = [[fr] for _ in range(C) for fr in (reversed(frames) if args.launch_order == "reversed" else frames)]
         S = len(chunk_sizes)
         opts_pipe = dict(opts)
-        if world >= 8:
-            opts_pipe.setdefault("grid_div", 2)
     else:
         # Frames in flight: never more lanes than steps (a lane that gets no timed step only adds set-up).  Ten lanes at
         # a quarter-size launch each were the best of {6, 10, 20} x grid_div {2, 4, 8} at the driver's K = 20
