@@ -297,21 +297,43 @@ def main():
                     help="experiment: idle the GPU this long between the warm-up steps and the timed bracket (DESIGN.md 6, first-process effect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-extra", action="store_true", help="N > 1: skip the irreg 4000x4000 sub-record")
+    ap.add_argument("--exchange", choices=["auto", "direct", "gather"], default="auto",
+                    help="N > 1: how the framebuffer reaches rank 0.  direct: every rank's kernel stores its pixels straight into rank 0's "
+                         "image (IPC mapping, over xGMI, while it renders); gather: one RCCL gather + an assembly launch behind the "
+                         "renders; auto: direct, checked against the oracle's checksums before anything is timed, else gather")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
+    # RT_SHARE_GPU=1: every rank uses cuda:0 and the gloo backend (host-staged gather) -- a test
+    # mode that runs the multi-rank control flow on a one-GPU box; never the measured configuration
+    share_gpu = bool(os.environ.get("RT_SHARE_GPU"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > torch.cuda.device_count() and not share_gpu:
+        # never a mislabelled smaller run: N GPUs were asked for, N must be there
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: become the N-rank job the contract describes (one process per GPU,
+        # torch.distributed over RCCL) instead of silently measuring one GPU
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        log(f"bench.py: --gpus {args.gpus} without a launcher: re-executing under torch.distributed.run ({args.gpus} ranks, 127.0.0.1:{port})")
+        sys.stderr.flush()
+        os.dup2(saved_stdout, 1)
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    # RT_SHARE_GPU=1: every rank uses cuda:0 and the gloo backend (host-staged gather) -- a test
-    # mode that runs the multi-rank control flow on a one-GPU box; never the measured configuration
-    share_gpu = bool(os.environ.get("RT_SHARE_GPU"))
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to print a "
+                         "line whose n_gpus is not what was asked for")
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -365,18 +387,25 @@ def main():
     # one "lane" per launch in flight: its own HIP stream, contexts, prepared scenes, framebuffers
     streams = [torch.cuda.current_stream(device)] if S == 1 else [torch.cuda.Stream(device) for _ in range(S)]
 
+    exchange = {"auto": "direct", "direct": "direct", "gather": "gather"}[args.exchange] if use_pg else "gather"
+
     class Lane:
-        """the renderers of one launch in flight + the step (render all, one gather, assemble)"""
+        """the renderers of one launch in flight + the step (render all, exchange, assemble)"""
         def __init__(self, o, fr=frames, nbatch=1):
             self.fr = fr
             self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in fr]
-            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch)
+            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch, exchange=exchange)
+            if exchange == "direct" and self.step.exchange_mode != "direct" and rank == 0:
+                log(f"bench.py: {self.step.exchange_note}")
 
-    lanes = []
-    for st, nb, fr in zip(streams, chunk_sizes, lane_frames):
-        with torch.cuda.stream(st):
-            lanes.append(Lane(opts_pipe, fr, nbatch=nb))
-    serial_lane = Lane(opts) if ((S > 1 or batch) and not args.no_serial_extra) else None   # on the default stream
+    def build_lanes():
+        ls = []
+        for st, nb, fr in zip(streams, chunk_sizes, lane_frames):
+            with torch.cuda.stream(st):
+                ls.append(Lane(opts_pipe, fr, nbatch=nb))
+        return ls, (Lane(opts) if ((S > 1 or batch) and not args.no_serial_extra) else None)   # (the serial lane: on the default stream)
+
+    lanes, serial_lane = build_lanes()
     torch.cuda.synchronize()
     renderers = [(scene, h, w, pr) for (scene, h, w), pr in zip(frames, serial_lane.prs if serial_lane else
                                                                  [next(ln.prs[0] for ln in lanes if ln.fr[0] == fr) for fr in frames] if batch else lanes[0].prs)]
@@ -469,6 +498,27 @@ def main():
     # untimed warm-up steps, then exactly K timed steps.
     for k in range(2 * S):
         step(k)
+    if use_pg and exchange == "direct":
+        # The direct-store exchange has only ever run on one GPU before the driver's multi-GPU box: check the set-up frames
+        # against the oracle's checksums NOW, and put every rank back on the RCCL gather if they are not right -- a wrong
+        # exchange must cost a fallback, not the run.
+        fence()
+        okt = torch.ones(1, dtype=torch.int32, device="cpu" if share_gpu else device)
+        if rank == 0:
+            try:
+                verify(lanes, "direct-store self-check,")
+            except SystemExit as e:
+                log(f"bench.py: direct stores failed their self-check, falling back to the RCCL gather:\n{e}")
+                okt.zero_()
+        dist.broadcast(okt, src=0)
+        if int(okt.item()) == 0 or any(ln.step.exchange_mode != "direct" for ln in lanes):
+            exchange = "gather"
+            for ln in lanes + ([serial_lane] if serial_lane else []):
+                ln.step.close()
+            lanes, serial_lane = build_lanes()
+            torch.cuda.synchronize()
+            for k in range(2 * S):
+                step(k)
     # Everything the host does for the FIRST time goes here, ahead of the warm-up steps, not between them and the bracket:
     # the first fill_ of a process loads torch's code object for it, and as the first GPU process of a fresh box (cold page
     # cache: what the driver's run is) that takes long enough for the idle GPU to drop its clock -- the timed launches then
@@ -503,16 +553,16 @@ def main():
         for (scene, h, w), pr in zip(frames, serial_lane.prs):
             ps2 = R.prepare_scene(h, w, pr.scene)              # a fresh prepared scene: no view has been seen
             img = torch.empty((h, w), dtype=torch.int32, device=device)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-            ev[0].record()
-            for k in range(4):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+            for k in range(4):      # render + sync, frame by frame (main.c:113-117): the view's policy arrives asynchronously
+                ev[k][0].record()
                 R.render_into(img.data_ptr(), h, w, ps2)
-                ev[k + 1].record()
-            torch.cuda.synchronize()
+                ev[k][1].record()
+                torch.cuda.synchronize()
             want = FRAME_CHECKSUM.get((scene, h, w))
             if want is not None and cks(img) != want:
                 raise SystemExit(f"VERIFICATION FAILED: first frames of {scene} {w}x{h}")
-            first[f"{scene}_{w}x{h}"] = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+            first[f"{scene}_{w}x{h}"] = [a.elapsed_time(b) for a, b in ev]
             # camera path: 20 frames, the prepared camera moved sideways a little more each frame, in one batch launch;
             # checked against the same cameras rendered one at a time
             nb = 20
@@ -631,6 +681,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "verified": True, "verified_images": n_verified,
+            "rccl_ranks": (dist.get_world_size() if (use_pg and not share_gpu) else 0),
+            "gather_mode": ("none (one GPU, whole frames)" if not use_pg else
+                            "direct-store: every rank's kernel stores its pixels into rank 0's image (IPC mapping) while it renders; "
+                            "two one-element all-reduces per launch order them" if lanes[0].step.exchange_mode == "direct" else
+                            "gather: one torch.distributed gather (RCCL) per launch + one assembly launch per scene")
+                           + (" [RT_SHARE_GPU test mode: gloo]" if share_gpu else ""),
             "value_protocol": (f"batched throughput: the {args.steps} steps' frames of each scene in {S // len(frames)} rt_render_batch "
                                f"launch(es) of {'/'.join(str(c) for c in chunk_sizes[::len(frames)])} frames (the scenes on separate "
                                "streams), all inside the timed bracket" if batch else
@@ -641,8 +697,7 @@ def main():
                        "options": opts_pipe, "protocol": args.protocol if batch or args.protocol == "lanes" else "lanes",
                        "launches_in_flight": S, "frames_per_launch": chunk_sizes,
                        "partition": ("one GPU: whole frames, no partition, no gather" if world == 1 and not use_pg else
-                                     f"cyclic 8-row tiles over {world} GPU(s), one RCCL gather to rank 0 per launch (all its frames), one "
-                                     "assembly launch per scene")
+                                     f"cyclic 8-row tiles over {world} GPU(s); exchange: see gather_mode")
                                     + (" [RT_SHARE_GPU test mode: ranks share cuda:0, gloo host-staged gather]" if share_gpu else "")},
             "per_scene": per_scene,
             "pipeline": {"avg_launches_in_flight": inflight,
@@ -678,8 +733,20 @@ def main():
                 if sc in MI100_RENDER_MS and (h, w) == (1000, 1000) and world == 1:
                     tg[sc] = {"mi100_ms": MI100_RENDER_MS[sc], "ms": skms[i], "speedup": MI100_RENDER_MS[sc] / skms[i],
                               "target_10x_met": MI100_RENDER_MS[sc] / skms[i] >= 10.0}
+            if cold is not None:
+                # the STATELESS figure (the reference's render keeps nothing between calls, ray.fut:246): a view never seen before
+                ff = cold["first_frames_ms"]
+                for sc in tg:
+                    c_ms = ff[f"{sc}_1000x1000"][0]
+                    tg[sc].update(cold_ms=c_ms, cold_speedup=MI100_RENDER_MS[sc] / c_ms, cold_target_10x_met=MI100_RENDER_MS[sc] / c_ms >= 10.0)
+                if all(f"{sc}_{w}x{h}" in ff for sc, h, w in frames):
+                    out["serial_cold_value"] = rays_step / sum(ff[f"{sc}_{w}x{h}"][0] for sc, h, w in frames) / 1e3
+                    out["serial"]["cold_value"] = out["serial_cold_value"]
+                    out["serial"]["cold_value_note"] = ("Mray/s with every frame the first of its view (no tile order, no deep-tile policy, no solo "
+                                                        "pixels; the frame also records its tile costs and sorts them): first_frames_ms[0] of each scene")
             if tg:
-                out["targets"] = {"note": ">= 10x the published MI100 Futhark render times (README.md:50), one frame at a time", **tg}
+                out["targets"] = {"note": ">= 10x the published MI100 Futhark render times (README.md:50), one frame at a time: `ms` a view "
+                                          "rendered before (warm), `cold_ms` a view never seen (the reference's render is stateless)", **tg}
         if scale_extra is not None:
             out["irreg_4000"] = scale_extra
         if world == 1 and not args.no_cpu_baseline:

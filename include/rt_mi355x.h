@@ -51,12 +51,15 @@ int rt_device_count(void);   /* usable HIP devices (0: none -- there is no CPU p
  * behaves like a single-device one on devices[0] -- scenes, prepare_scene, render, sync, values -- but
  * prepare_scene replicates the scene on every device and rt_render / rt_render_image cut the frame into
  * cyclic tiles of 8 rows (part i of ndev on devices[i]) and gather the parts on devices[0]: RCCL
- * point-to-point over xGMI (librccl is loaded on demand), or peer copies (option "gather": 0 auto, 1 peer
- * copies, 2 RCCL).  A device may be listed more than once (peer copies only): that is how the fan-out is
- * tested on a one-GPU box.  rt_render_part with nparts > 1 is refused on such a context. */
+ * point-to-point over xGMI (librccl is loaded on demand), peer copies, or -- option "gather" = 3 -- no gather at
+ * all: every device stores its pixels straight into the image on devices[0] over xGMI while it renders (peer
+ * access; rt_render_part_inplace).  Option "gather": 0 auto (direct stores when every device can reach devices[0],
+ * else RCCL, else peer copies), 1 peer copies, 2 RCCL, 3 direct stores.  A device may be listed more than once
+ * (no RCCL then): that is how the fan-out is tested on a one-GPU box.  rt_render_part with nparts > 1 is refused
+ * on such a context. */
 int rt_context_create_multi(rt_context **out, const int *devices, int ndev);
 int rt_context_num_devices(const rt_context *ctx);          /* 1 for an ordinary context */
-const char *rt_context_gather_mode(rt_context *ctx);        /* "none", "rccl" or "peer-copy" (static strings) */
+const char *rt_context_gather_mode(rt_context *ctx);        /* "none", "direct-store", "rccl" or "peer-copy" (static strings) */
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
 int rt_context_sync(rt_context *ctx);
@@ -117,6 +120,22 @@ int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t width, int
  * framebuffer gather moves nframes x part per device, one assembly launch writes the nframes images. */
 int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                     int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride, int32_t *out_dev);
+/* The same part of the same frames, but stored IN PLACE: image_dev is the FULL image (frame f at image_dev + f *
+ * frame_stride, frame_stride >= h * w; 0 = h * w for one frame) and every pixel of the part goes to its place in it
+ * -- no packed part buffer, no gather, no assembly launch.  image_dev may be memory of ANOTHER device of the node
+ * (a peer allocation, or a buffer of another process mapped with rt_ipc_import): the 4-byte pixel stores then are
+ * the framebuffer exchange of SURVEY.md 8(e) -- they cross xGMI while the frame is being traced instead of in a
+ * gather behind it (futhark/main.c:107-135 has nothing to correspond: the reference is a single device).  The
+ * caller orders the consumers of the image behind every part's stream (event, collective, barrier). */
+int rt_render_part_inplace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                           int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
+                           int32_t *image_dev);
+/* One process per GPU: the owner of an image exports the allocation (a pointer rt_device_alloc returned) as 64
+ * opaque bytes (hipIpcMemHandle_t), the other processes import them and get a device pointer usable as image_dev
+ * above; rt_ipc_close unmaps it (before the owner frees the buffer). */
+int rt_ipc_export(rt_context *ctx, void *dev, unsigned char handle64[64]);
+int rt_ipc_import(rt_context *ctx, const unsigned char handle64[64], void **out_dev);
+int rt_ipc_close(rt_context *ctx, void *imported_dev);
 int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);
 /* Scatter one part's packed rows into a full h*w image on the device (rank-0 side of
  * the framebuffer gather). */

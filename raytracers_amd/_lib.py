@@ -18,7 +18,7 @@ RT_SYMBOLS = [
     "rt_scene_free",
     "rt_prepare_scene", "rt_prepared_free", "rt_prepared_num_spheres", "rt_prepared_height", "rt_prepared_get_bvh",
     "rt_prepared_get_camera",
-    "rt_render", "rt_render_part", "rt_render_image", "rt_render_batch", "rt_part_rows", "rt_place_part", "rt_place_parts", "rt_place_parts_strided", "rt_place_parts_batch", "rt_render_stats", "rt_render_trace",
+    "rt_render", "rt_render_part", "rt_render_image", "rt_render_batch", "rt_render_part_inplace", "rt_ipc_export", "rt_ipc_import", "rt_ipc_close", "rt_part_rows", "rt_place_part", "rt_place_parts", "rt_place_parts_strided", "rt_place_parts_batch", "rt_render_stats", "rt_render_trace",
     "rt_render_timed",
     "rt_device_alloc", "rt_device_free", "rt_copy_to_host",
 ]
@@ -79,6 +79,10 @@ def _load():
         "rt_render_part": (C.c_int, [vp, vp, i64, i64, i32, i32, i32, i32, vp]),
         "rt_render_image": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, i32, i32, vp]),
         "rt_render_batch": (C.c_int, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, i64, vp]),
+        "rt_render_part_inplace": (C.c_int, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, i64, vp]),
+        "rt_ipc_export": (C.c_int, [vp, vp, vp]),
+        "rt_ipc_import": (C.c_int, [vp, vp, C.POINTER(vp)]),
+        "rt_ipc_close": (C.c_int, [vp, vp]),
         "rt_part_rows": (i64, [i64, i32, i32, i32]),
         "rt_place_part": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, vp]),
         "rt_place_parts": (C.c_int, [vp, i64, i64, i32, i32, i64, vp, vp]),

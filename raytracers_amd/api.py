@@ -129,6 +129,15 @@ class DeviceBuffer:
         ctx._check(lib.rt_device_alloc(ctx._h, C.byref(p), nbytes))
         self.ptr = p.value
 
+    def as_torch(self, shape):
+        """zero-copy torch int32 view of the buffer (the buffer must outlive it)"""
+        import torch
+        n = int(np.prod(shape))
+        assert n * 4 <= self.nbytes
+        iface = {"shape": tuple(int(x) for x in shape), "typestr": "<i4", "data": (int(self.ptr), False), "version": 2}
+        holder = type("_CudaArray", (), {"__cuda_array_interface__": iface})()
+        return torch.as_tensor(holder, device="cuda")
+
     def to_host(self, shape):
         out = np.empty(shape, dtype=np.int32)
         assert out.nbytes <= self.nbytes
@@ -255,6 +264,42 @@ def render_batch_into(out_ptr, h, w, prepared, nframes, frame_stride=None, cams=
         cp = c.ctypes.data
     ctx._check(lib.rt_render_batch(ctx._h, prepared._h, int(h), int(w), int(max_depth), int(rows_per_tile), int(part), int(nparts),
                                    int(nframes), C.c_void_p(cp), int(frame_stride), C.c_void_p(out_ptr)))
+
+
+def render_inplace_into(image_ptr, h, w, prepared, nframes=1, frame_stride=None, cams=None, max_depth=MAX_DEPTH, part=0, nparts=1,
+                        rows_per_tile=ROWS_PER_TILE):
+    """Part `part` of `nparts` of `nframes` frames stored IN PLACE (rt_render_part_inplace): image_ptr is the FULL image
+    (frame f at image_ptr + 4 * f * frame_stride, default h * w) -- possibly another device's memory (a peer allocation or
+    an ipc_import'ed buffer): the pixel stores then are the framebuffer exchange."""
+    ctx = prepared.ctx
+    cp = None
+    if cams is not None:
+        c = np.ascontiguousarray(cams, dtype=np.float32)
+        assert c.size == 12 * nframes
+        cp = c.ctypes.data
+    ctx._check(lib.rt_render_part_inplace(ctx._h, prepared._h, int(h), int(w), int(max_depth), int(rows_per_tile), int(part), int(nparts),
+                                          int(nframes), C.c_void_p(cp), int(h * w if frame_stride is None else frame_stride),
+                                          C.c_void_p(image_ptr)))
+
+
+def ipc_export(ctx, dev_ptr):
+    """64 opaque bytes naming the device allocation at dev_ptr (a DeviceBuffer's pointer) for the other processes of the node"""
+    h = (C.c_ubyte * 64)()
+    ctx._check(lib.rt_ipc_export(ctx._h, C.c_void_p(dev_ptr), h))
+    return bytes(h)
+
+
+def ipc_import(ctx, handle64):
+    """a device pointer to another process's exported allocation (valid until ipc_close)"""
+    assert len(handle64) == 64
+    h = (C.c_ubyte * 64).from_buffer_copy(handle64)
+    p = C.c_void_p()
+    ctx._check(lib.rt_ipc_import(ctx._h, h, C.byref(p)))
+    return p.value
+
+
+def ipc_close(ctx, dev_ptr):
+    ctx._check(lib.rt_ipc_close(ctx._h, C.c_void_p(dev_ptr)))
 
 
 def render(h, w, prepared, max_depth=MAX_DEPTH):

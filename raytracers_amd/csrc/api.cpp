@@ -232,7 +232,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
 
 // Which tiles of an ordered view are "deep" (their waves do not refill while they trace them) and in how many pieces the
 // deepest ones are handed out.  deep_class >= 0: as configured.  Auto (-1), from the view's class table (tiles with a bounce
-// chain of >= 32 / 16 / 8 scatters: read back once per view, the first time the view is rendered with its order):
+// chain of >= 32 / 16 / 8 scatters; it reaches the host asynchronously, see deep_policy):
 //   * a frame of at most 32768 tiles whose tiles with chains of >= 8 (or >= 16) bounces would park only a few per cent of
 //     the launch's wave time if each of them kept a wave to itself (irreg 1000x1000: ~700 of 15 625 tiles; weight = sum
 //     of chain-length classes <= 2.5 per wave): all of them are deep, and the deepest waves / 64 tiles go out PIXEL BY
@@ -248,13 +248,30 @@ struct DeepPolicy {
   int deep_class, deep_split, cap_log2;
   bool sparse;
 };
-int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves_full, DeepPolicy *dp) {
+// The class table reaches the host without any render entry waiting for it: the frame that sorts a view's tiles enqueues a
+// copy of the table into a pinned slot (request_classes, below), and a later render of the view adopts it once that copy
+// has completed -- until then the view runs on the default setting (same pixels; a caller that syncs after every frame, as
+// the reference's harness does, has the policy from the view's second frame on, one that enqueues frames back to back a
+// few frames later).  `may_wait`: the diagnostic entry (rt_render_trace), which synchronises anyway.
+int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves_full, DeepPolicy *dp, bool may_wait = false) {
   *dp = DeepPolicy{ctx->deep_class < 0 ? 3 : ctx->deep_class, ctx->deep_split, ctx->deep_cap_log2, false};
   if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1) return 0;
   if (!to->have_classes) {
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(to->classes, to->order + to->ntiles, sizeof to->classes, hipMemcpyDeviceToHost));
-    to->have_classes = true;
+    if (to->classes_pending && ps->classes_pinned && to->classes_slot >= 0) {
+      hipError_t q = may_wait ? hipEventSynchronize(to->classes_event) : hipEventQuery(to->classes_event);
+      if (q == hipSuccess) {
+        std::memcpy(to->classes, ps->classes_pinned + kClassSlotInts * to->classes_slot, sizeof to->classes);
+        to->have_classes = true;
+        to->classes_pending = false;
+      } else {
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+      }
+    } else if (may_wait) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      RT_HIP(ctx, hipMemcpy(to->classes, to->order + to->ntiles, sizeof to->classes, hipMemcpyDeviceToHost));
+      to->have_classes = true;
+    }
+    if (!to->have_classes) return 0;
   }
   if (!ctx->solo || ps->tl_depth != rtk::kTreeletDepth) return 0;
   const int64_t t3 = to->classes[3], t4 = to->classes[4], t5 = to->classes[5];
@@ -265,11 +282,35 @@ int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves
   return 0;
 }
 
+// Behind the tile-order sort of a view: its class table on its way to the host (stream-ordered copy into the view's pinned
+// slot + an event).  Nothing waits here.
+int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
+  rt_prepared *ps = const_cast<rt_prepared *>(ps_c);   // (the orders are `mutable` state of a prepared scene; so is their landing area)
+  to->classes_pending = false;
+  if (ctx->deep_class >= 0 || to->nshards != 1) return 0;   // no policy reads the table
+  if (!ps->classes_pinned)
+    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * kClassSlotInts * kClassSlots, hipHostMallocDefault));
+  if (to->classes_slot < 0) {
+    unsigned used = 0;
+    for (const auto &o : ps->orders)
+      if (o.classes_slot >= 0) used |= 1u << o.classes_slot;
+    for (int sl = 0; sl < kClassSlots && to->classes_slot < 0; ++sl)
+      if (!(used >> sl & 1u)) to->classes_slot = sl;
+    if (to->classes_slot < 0) return 0;   // (cannot happen: at most kClassSlots views are kept)
+  }
+  if (!to->classes_event) RT_HIP(ctx, hipEventCreateWithFlags(&to->classes_event, hipEventDisableTiming));
+  RT_HIP(ctx, hipMemcpyAsync(ps->classes_pinned + kClassSlotInts * to->classes_slot, to->order + to->ntiles, sizeof to->classes,
+                             hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipEventRecord(to->classes_event, ctx->stream));
+  to->classes_pending = true;
+  return 0;
+}
+
 }  // namespace
 
 int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                         int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12, int32_t nframes,
-                        int64_t frame_stride, const float *cams_dev) {
+                        int64_t frame_stride, const float *cams_dev, bool inplace) {
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
   if (!out_dev) return fail(ctx, "null output pointer");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30))
@@ -296,13 +337,29 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.stats = ctx->stats_dev;
   p.nframes = 1;
   if (p.rows_local == 0) return 0;
-  if (nframes < 1 || (nframes > 1 && (frame_stride < static_cast<int64_t>(p.rows_local) * p.w ||
-                                     frame_stride * nframes >= (int64_t(1) << 31))))
-    return fail(ctx, "bad batch: nframes >= 1, frame_stride >= rows * w, nframes * frame_stride < 2^31");
+  const int64_t frame_elems = inplace ? h * w : static_cast<int64_t>(p.rows_local) * p.w;
+  if (nframes < 1 || (nframes > 1 && (frame_stride < frame_elems || frame_stride * nframes >= (int64_t(1) << 31))))
+    return fail(ctx, "bad batch: nframes >= 1, frame_stride >= rows * w (in place: h * w), nframes * frame_stride < 2^31");
+  if (inplace) {
+    // the part's row tile k (rows_per_tile rows) starts at image row (k * nparts + part) * rows_per_tile: k * rows_per_tile
+    // of that is the packed position the kernels compute anyway, `part * rows_per_tile` goes into the base pointer, the rest
+    // -- k * (nparts - 1) * rows_per_tile rows -- is k * out_skip
+    p.out = out_dev + static_cast<int64_t>(part) * rows_per_tile * w;
+    p.out_skip = static_cast<int>(static_cast<int64_t>(nparts - 1) * rows_per_tile * w);
+  }
   if (max_depth == 0) {
     // `while depth < 0`: no ray is traced, every pixel is the initial colour (0,0,0)
-    for (int f = 0; f < nframes; ++f)
-      RT_HIP(ctx, hipMemsetAsync(out_dev + f * frame_stride, 0, sizeof(int32_t) * static_cast<size_t>(p.rows_local) * p.w, ctx->stream));
+    for (int f = 0; f < nframes; ++f) {
+      if (!inplace) {
+        RT_HIP(ctx, hipMemsetAsync(out_dev + f * frame_stride, 0, sizeof(int32_t) * static_cast<size_t>(p.rows_local) * p.w, ctx->stream));
+        continue;
+      }
+      for (int64_t k = 0; k * rows_per_tile < p.rows_local; ++k) {   // the part's row tiles, one by one, at their places
+        const int64_t rows = std::min<int64_t>(rows_per_tile, p.rows_local - k * rows_per_tile);
+        RT_HIP(ctx, hipMemsetAsync(out_dev + f * frame_stride + (k * nparts + part) * rows_per_tile * w, 0,
+                                   sizeof(int32_t) * static_cast<size_t>(rows * w), ctx->stream));
+      }
+    }
     return 0;
   }
   Plan pl{};
@@ -318,7 +375,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     for (int f = 0; f < nframes; ++f)
       if (int rc = enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev + f * frame_stride, stats,
-                                  cams_dev ? hc.data() + 12 * f : cam12))
+                                  cams_dev ? hc.data() + 12 * f : cam12, 1, 0, nullptr, inplace))
         return rc;
     return 0;
   }
@@ -382,6 +439,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           for (size_t i = 1; i < ps->orders.size(); ++i)
             if (ps->orders[i].stamp < ps->orders[lru].stamp) lru = i;
           TileOrder &v = ps->orders[lru];
+          o.classes_event = v.classes_event;   // (a copy still in flight lands in the slot before any later one: same stream)
+          o.classes_slot = v.classes_slot;
           if (v.ntiles == p.nchunks) {
             o.cost = v.cost;
             o.order = v.order;
@@ -416,7 +475,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.deep_class = dp.deep_class;
       p.deep_split = dp.deep_split;
       p.deep_cap_log2 = dp.cap_log2;
-      if (dp.sparse && ctx->grid_div == 0) pl.grid = pl.grid_full;
+      if (dp.sparse && ctx->grid_div == 0 && pl.grid != pl.grid_full) {
+        pl.grid = pl.grid_full;
+        // the queue layout follows the grid that is launched -- as long as the view's order table (laid out for
+        // `order_shards` shards) still fits it
+        const int ns = (xq && (nframes == 1 || xq == 2) && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+        const int il = ns > 1 && xq == 2;
+        if ((il ? 1 : ns) == order_shards) { p.nshards = ns; p.interleave = il; }
+      }
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
@@ -425,6 +491,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
       to->valid = true;
       to->have_classes = false;
+      if (int rc = request_classes(ctx, ps, to)) return rc;
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
@@ -651,7 +718,7 @@ extern "C" int rt_scene_floor(rt_context *ctx, rt_scene **out, int n, float k) {
 extern "C" int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7, int64_t n,
                                      const float look_from[3], const float look_at[3], float fov) {
   if (!spheres7 || !look_from || !look_at) return fail(ctx, "null argument");
-  if (n < 2 || n > (int64_t(1) << 26)) return fail(ctx, "scene needs 2 .. 2^26 spheres");
+  if (n < 2 || n > (int64_t(1) << rtk::kMaxSpheresLog2)) return fail(ctx, "scene needs 2 .. 2^26 spheres");   // (treelet.h: the builders' index fields)
   rt::SceneDesc d;
   d.spheres.resize(static_cast<size_t>(n));
   std::memcpy(d.spheres.data(), spheres7, sizeof(rt::Sphere) * static_cast<size_t>(n));
@@ -803,7 +870,9 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   for (auto &o : ps->orders) {
     (void)hipFree(o.cost);
     (void)hipFree(o.order);
+    if (o.classes_event) (void)hipEventDestroy(o.classes_event);
   }
+  if (ps->classes_pinned) (void)hipHostFree(ps->classes_pinned);
   delete ps;
   return 0;
 }
@@ -871,14 +940,15 @@ int rti::stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const
   RT_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = sizeof(float) * 12 * static_cast<size_t>(nframes);
   if (bytes > ctx->cams_bytes) {
+    // grow: the stream is drained first, so nothing reads the old blocks any more; the event object is kept (it is
+    // re-recorded below) -- only its "an upload is pending" meaning lapses with the old pinned block
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
-  if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
-  if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
     if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
     ctx->cams_dev = nullptr;
     ctx->cams_host = nullptr;
     ctx->cams_bytes = 0;
+    ctx->cams_event_valid = false;
     RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cams_dev), bytes));
     RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->cams_host), bytes, hipHostMallocDefault));
     ctx->cams_bytes = bytes;
@@ -907,6 +977,51 @@ extern "C" int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h
   const float *cams_dev = nullptr;
   if (int rc = rti::stage_cams(ctx, cams12, nframes, &cams_dev)) return rc;
   return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, out_dev, false, nullptr, nframes, frame_stride, cams_dev);
+}
+
+// A part's rows of `nframes` frames stored straight into the FULL images (no packed part buffer, no gather, no assembly):
+// image_dev may be memory of another device of the node -- a peer allocation, or another process's buffer mapped with
+// rt_ipc_import -- and the pixel stores then are the framebuffer exchange, travelling over xGMI while the frame is traced.
+extern "C" int rt_render_part_inplace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
+                                      int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
+                                      int32_t *image_dev) {
+  if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
+  if (ctx->group) return fail(ctx, "a multi-device context renders whole frames: it partitions them itself (option gather=3 stores in place)");
+  if (nframes < 1 || nframes > 4096) return fail(ctx, "rt_render_part_inplace: 1 .. 4096 frames");
+  if (nframes == 1)   // (one frame: its camera travels in the kernel arguments)
+    return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, image_dev, false, cams12, 1, h * w, nullptr, true);
+  const float *cams_dev = nullptr;
+  if (int rc = rti::stage_cams(ctx, cams12, nframes, &cams_dev)) return rc;
+  return enqueue_render(ctx, ps, h, w, max_depth, rows_per_tile, part, nparts, image_dev, false, nullptr, nframes, frame_stride, cams_dev, true);
+}
+
+// Sharing a device buffer between the processes of one node (one process per GPU): the owner exports the allocation
+// (rt_device_alloc's pointer, i.e. the base of a hipMalloc block) as 64 opaque bytes, the other ranks import them and get a
+// device pointer they can hand to rt_render_part_inplace.
+extern "C" int rt_ipc_export(rt_context *ctx, void *dev, unsigned char handle64[64]) {
+  if (!ctx || !dev || !handle64) return fail(ctx, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI passes an IPC handle as 64 bytes");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  hipIpcMemHandle_t hnd;
+  RT_HIP(ctx, hipIpcGetMemHandle(&hnd, dev));
+  std::memcpy(handle64, &hnd, 64);
+  return 0;
+}
+extern "C" int rt_ipc_import(rt_context *ctx, const unsigned char handle64[64], void **out_dev) {
+  if (!ctx || !handle64 || !out_dev) return fail(ctx, "null argument");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  hipIpcMemHandle_t hnd;
+  std::memcpy(&hnd, handle64, 64);
+  RT_HIP(ctx, hipIpcOpenMemHandle(out_dev, hnd, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+extern "C" int rt_ipc_close(rt_context *ctx, void *imported_dev) {
+  if (!ctx) return 1;
+  if (!imported_dev) return 0;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipIpcCloseMemHandle(imported_dev));
+  return 0;
 }
 
 extern "C" int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts) {
@@ -1049,7 +1164,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
         p.order = o.order;
         DeepPolicy dp;
-        if (deep_policy(ctx, ps, &o, pl.grid_full * pl.waves, &dp)) rc = 1;
+        if (deep_policy(ctx, ps, &o, pl.grid_full * pl.waves, &dp, true)) rc = 1;
         p.deep_class = dp.deep_class;
         p.deep_split = dp.deep_split;
         p.deep_cap_log2 = dp.cap_log2;

@@ -14,8 +14,12 @@
 //     per device, grouped ncclSend (child stream, right behind the render) / ncclRecv (parent stream)
 //     straight into the part's slice of the stacked buffer -- point-to-point over xGMI, 7 links into
 //     device 0 in parallel; nothing is reduced, so no ring collective is involved;
-//   * peer copies (hipMemcpyPeerAsync on the child's stream; also the fallback, and the only mode
-//     for a device list with repeats, which exists to test the fan-out on a one-GPU box).
+//   * peer copies (hipMemcpyPeerAsync on the child's stream; also the fallback for a failing RCCL);
+//   * DIRECT STORES (gather = 3; what "auto" picks when every device can reach the first one): no part buffers, no
+//     gather, no assembly launch -- every device's kernel stores its finished pixels at their places in the caller's image
+//     on the first device (rt_render_part_inplace's layout; peer access over xGMI).  The 4-byte pixel stores leave a device
+//     while it is still tracing, so the exchange is off the frame's critical path: behind the slowest device's kernel there
+//     is only an event.  (Modelled, tools/scale_prediction.py: irreg 4000x4000 on 8 devices 516 -> ~420 us per frame.)
 // librccl is loaded on demand (dlopen): the single-device library has no RCCL dependency.
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: librccl itself is dlopen'ed at the first multi-device frame
@@ -31,7 +35,10 @@ struct rt_group {
   std::vector<rt_context *> kids;   // one per device entry, own stream each
   std::vector<int> devices;
   bool distinct = true;
-  int gather = 0;                   // 0 auto, 1 peer copies, 2 RCCL (then part 0 goes through RCCL too)
+  int gather = 0;                   // 0 auto, 1 peer copies, 2 RCCL (then part 0 goes through RCCL too), 3 direct stores into the image on the first device
+  bool peer_ok = true;              // every device can store into the first device's memory (peer access enabled, or the same device)
+  hipEvent_t ev_begin = nullptr;    // direct stores: the parent stream's position when the frame was asked for (the image's previous readers)
+  bool last_direct = false;         // what carried the last frame (rt_context_gather_mode)
   // gather buffers, grown on demand
   int64_t buf_elems = 0;            // capacity of one part in int32
   std::vector<int32_t *> part;      // part[i] on device i (kid 0 renders into the stacked buffer unless gather == 2)
@@ -134,17 +141,23 @@ extern "C" int rt_context_create_multi(rt_context **out, const int *devices, int
     rt_context *kid = nullptr;
     if (int rc = rt_context_create(&kid, devices[i], nullptr, 0)) return bail(rc, "cannot create a context on device " + std::to_string(devices[i]));
     g->kids.push_back(kid);
-    if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&g->ev_part[static_cast<size_t>(i)], hipEventDisableTiming) != hipSuccess)
+    // (system-scope release: what a device stored into the first device's memory must be visible there once the event has passed)
+    if (hipSetDevice(devices[i]) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_part[static_cast<size_t>(i)], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
       return bail(8, "hipEventCreate failed");
     if (devices[i] != devices[0]) {
       // direct xGMI access both ways (an already enabled pair reports an error that is not one)
-      (void)hipDeviceEnablePeerAccess(devices[0], 0);
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) != hipSuccess || !can) g->peer_ok = false;
+      const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) g->peer_ok = false;
       (void)hipSetDevice(devices[0]);
       (void)hipDeviceEnablePeerAccess(devices[i], 0);
       (void)hipGetLastError();
     }
   }
-  if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->ev_placed, hipEventDisableTiming) != hipSuccess)
+  if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->ev_placed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_begin, hipEventDisableTiming) != hipSuccess)
     return bail(8, "hipEventCreate failed");
   *out = parent;
   return 0;
@@ -158,6 +171,7 @@ extern "C" int rt_context_num_devices(const rt_context *ctx) {
 extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
   if (!ctx || !ctx->group || ctx->group->kids.size() < 2) return ctx && ctx->group && ctx->group->gather == 2 ? "rccl" : "none";
   rt_group *g = ctx->group;
+  if (g->gather == 3 || (g->gather == 0 && g->peer_ok)) return "direct-store";
   if (g->gather == 1 || g->rccl_failed || !g->distinct) return "peer-copy";
   if (!g->rccl_tried) return "rccl (loaded at the first frame; peer copies if that fails)";   // (a getter creates no communicators)
   return g->comms.empty() ? "peer-copy" : "rccl";
@@ -178,6 +192,7 @@ void rti::group_destroy(rt_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (g->stacked) (void)hipFree(g->stacked);
   if (g->ev_placed) (void)hipEventDestroy(g->ev_placed);
+  if (g->ev_begin) (void)hipEventDestroy(g->ev_begin);
   // librccl stays loaded: unloading a library that owns device state at exit time is asking for trouble
   delete g;
   ctx->group = nullptr;
@@ -218,7 +233,8 @@ int rti::group_set_variant(rt_context *ctx, int variant) {
 
 int rti::group_set_option(rt_context *ctx, const char *name, int64_t value) {
   if (std::strcmp(name, "gather") == 0) {
-    if (value < 0 || value > 2) return fail(ctx, "gather must be 0 (auto), 1 (peer copies) or 2 (RCCL)");
+    if (value < 0 || value > 3) return fail(ctx, "gather must be 0 (auto), 1 (peer copies), 2 (RCCL) or 3 (direct stores into the first device's image)");
+    if (value == 3 && !ctx->group->peer_ok) return fail(ctx, "gather=3 (direct stores): a device of this context cannot access the first device's memory");
     if (int rc = rti::group_sync(ctx)) return rc;
     ctx->group->gather = static_cast<int>(value);
     return 0;
@@ -269,6 +285,27 @@ int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t
   if (nframes < 1 || (nframes > 1 && (frame_stride < h * w || frame_stride * nframes >= (int64_t(1) << 31))))
     return fail(ctx, "bad batch: nframes >= 1, frame_stride >= h * w, nframes * frame_stride < 2^31");
   constexpr int32_t kRows = 8;
+  if (g->gather == 3 || (g->gather == 0 && g->peer_ok)) {
+    // ---- direct stores: every device writes its rows where the image has them; nothing is gathered or assembled ----
+    // (the image's previous readers sit on the parent's stream: the devices start behind them)
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventRecord(g->ev_begin, ctx->stream));
+    const int64_t fs = nframes > 1 ? frame_stride : h * w;
+    for (int i = 0; i < n; ++i) {
+      rt_context *kid = g->kids[static_cast<size_t>(i)];
+      RT_HIP(ctx, hipSetDevice(kid->device));
+      RT_HIP(ctx, hipStreamWaitEvent(kid->stream, g->ev_begin, 0));
+      const rt_prepared *kps = i == 0 ? ps : ps->replicas[static_cast<size_t>(i)];
+      const float *cams_dev = nullptr;
+      if (nframes > 1 && rti::stage_cams(kid, cams12, nframes, &cams_dev)) return fail(ctx, rt_last_error(kid));
+      if (rti::enqueue_render(kid, kps, h, w, max_depth, kRows, i, n, out_dev, false, cam12, nframes, fs, cams_dev, true))
+        return fail(ctx, rt_last_error(kid));
+      RT_HIP(ctx, hipEventRecord(g->ev_part[static_cast<size_t>(i)], kid->stream));
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; ++i) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ev_part[static_cast<size_t>(i)], 0));
+    return 0;
+  }
   const bool want_rccl = !g->rccl_failed && (g->gather == 2 || (g->gather == 0 && n > 1));
   bool rccl = want_rccl && load_rccl(g);
   if (g->gather == 2 && !rccl) return fail(ctx, "gather=2 (RCCL) requested but unavailable: " + (g->rccl_failed ? std::string("it failed at run time") : g->rccl_note));

@@ -49,6 +49,11 @@ __device__ __forceinline__ int global_row(const KParams &p, int lrow) {
   return (k * p.nparts + p.part) * p.rows_per_tile + (lrow - k * p.rows_per_tile);
 }
 
+// where a pixel of this part is stored: packed rows, or (out_skip != 0) its place in the full image
+__device__ __forceinline__ size_t out_index(const KParams &p, int lrow, int col) {
+  return (size_t)lrow * p.w + col + (size_t)(lrow / p.rows_per_tile) * (size_t)p.out_skip;
+}
+
 // ---------------------------------------------------------------------------------
 // Family 1: one thread per pixel.
 // ---------------------------------------------------------------------------------
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64) void pixel_kernel(KParams p) {
     }
     if (!finish_ray(r, best, bestj, s.x, s.y, s.z, s.w, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) break;
   }
-  p.out[(size_t)lrow * p.w + col] = pixel;
+  p.out[out_index(p, lrow, col)] = pixel;
   if (STATS) {
     atomicAdd(&p.stats[0], n_rays);
     atomicAdd(&p.stats[1], n_box);
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(THREADS) void persistent_kernel(KParams p) {
           bestj = -1;
           if (STATS) n_rays++;
         } else {
-          p.out[pix] = pixel;
+          const int lr_ = pix / p.w;
+          p.out[out_index(p, lr_, pix - lr_ * p.w)] = pixel;
           pix = -1;
         }
       }
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         Ray pr;
         primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
         solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
-                   pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col, 0, tile);
+                   pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, tile);
       }
     }
   }
@@ -778,10 +784,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               const int within = (int)((q_next + rank) & 63u);
               const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
               if (col < p.w && lrow < p.rows_local) {
-                slot = q_frame_off + lrow * p.w + col;
-                ptile = q_tile;
                 // cyclic row tiles with rows_per_tile = 1 << rpt_log2 (division-free global_row)
                 const int k = lrow >> p.rpt_log2;
+                slot = q_frame_off + lrow * p.w + col + k * p.out_skip;   // (out_skip: 0 packed, else the pixel's place in the full image)
+                ptile = q_tile;
                 const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
                 primary_dir_uv(q_cam, p.u_tab[col], p.v_tab[grow], r);
                 want = false;

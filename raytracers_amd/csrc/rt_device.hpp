@@ -167,6 +167,10 @@ struct KParams {
   int tiles_y;           // ceil(rows_local / 8) (nchunks = tiles_x * tiles_y; on the host: no integer division in the kernel)
   int max_depth;
   int32_t *out;          // [rows_local * w]  (batch launch: frame f at out + f * frame_stride)
+  int out_skip;          // 0: the part's rows are PACKED at out.  In place (rt_render_part_inplace): out = the full image's row
+                         // part * rows_per_tile, and the part's row tile k lies k * out_skip = k * (nparts - 1) * rows_per_tile * w
+                         // elements further than in the packed layout -- every pixel is stored where the assembled image has it
+                         // (that image may be another device's memory: the stores then are the framebuffer exchange)
   int nframes;           // pooled family: frames rendered by this one launch (>= 1)
   int tpt_log2;          // pooled family: a ticket of the tile queue covers 1 << tpt_log2 consecutive tiles
   int frame_stride;      // int32 elements between consecutive frames' buffers

@@ -105,7 +105,13 @@ struct TileOrder {
   uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
   bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
   int classes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // ... which arrives ASYNCHRONOUSLY: the frame that computes the table enqueues a copy of it into a pinned slot and records
+  // `classes_event`; a later render takes it over once the event has completed (no render entry ever waits for the device)
+  int classes_slot = -1;             // slot of rt_prepared::classes_pinned
+  hipEvent_t classes_event = nullptr;
+  bool classes_pending = false;
 };
+constexpr int kClassSlotInts = 16, kClassSlots = 8;   // per prepared scene: one pinned slot per kept view
 
 struct rt_prepared {
   mutable std::vector<TileOrder> orders;
@@ -123,6 +129,7 @@ struct rt_prepared {
   char *block = nullptr;   // one device allocation behind all of the arrays above
   size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables (allocated with the first ordered view)
   std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
   std::vector<std::future<int>> replica_jobs;   // ... while they are being built (rt_prepare_scene joins them)
 };
@@ -132,9 +139,11 @@ namespace rti {
 int fail(rt_context *ctx, const std::string &msg);
 int hip_fail(rt_context *ctx, hipError_t e, const char *what);
 // Enqueue one part of a frame on ctx's stream (single device).  cam12 == nullptr: the prepared camera.
+// inplace: out_dev is the FULL image (frame f at out_dev + f * frame_stride, frame_stride >= h * w) and the part's rows are
+// stored at their places in it instead of packed.
 int enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                    int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12 = nullptr, int32_t nframes = 1,
-                   int64_t frame_stride = 0, const float *cams_dev = nullptr);
+                   int64_t frame_stride = 0, const float *cams_dev = nullptr, bool inplace = false);
 // multi_gpu.cpp
 // (nframes > 1: a batch -- frame f to out_dev + f * frame_stride, through cams12 + 12 f when cams12 is given)
 int group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t *out_dev,

@@ -61,8 +61,12 @@ RT_TL_HD TlMasks tl_masks(uint32_t occ, int h, int D) {
 
 // The GPU builder (bvh_build.hip) numbers the cut of depth 2 without the general machinery: a node of odd depth sits
 // right behind its parent (position 1, or 2 for a right child whose left sibling is an inner node too).  It carries a
-// node's place next to its traversal index: index in bits 0..23, then odd depth, right child, position (2 bits).
-constexpr int kTlIndexBits = 24;
+// node's place next to its traversal index: index in bits 0..26, then odd depth, right child, position (2 bits); bit 31
+// stays clear (the place is also carried in signed ints).  rt_scene_from_spheres admits at most 2^kMaxSpheresLog2 spheres:
+// every inner-node index then fits the index field.
+constexpr int kMaxSpheresLog2 = 26;
+constexpr int kTlIndexBits = 27;
+static_assert(kTlIndexBits > kMaxSpheresLog2 && kTlIndexBits + 4 <= 31, "a node's place: index field + 4 flag bits in a non-negative int");
 constexpr uint32_t kTlIndexMask = (1u << kTlIndexBits) - 1u;
 RT_TL_HD uint32_t tl_pack_place(uint32_t index, bool odd, bool is_right, int pos) {
   return index | (odd ? 1u << kTlIndexBits : 0u) | (is_right ? 2u << kTlIndexBits : 0u) | ((uint32_t)pos << (kTlIndexBits + 2));

@@ -61,6 +61,12 @@ class HipPartRenderer:
                               max_depth=self.max_depth, part=part, nparts=nparts)
         return out
 
+    def inplace(self, part, nparts, nbatch, image_ptr, frame_stride):
+        """this rank's rows of `nbatch` frames stored at their places in the FULL image(s) at device pointer image_ptr
+        (rt_render_part_inplace) -- possibly another rank's buffer (ipc_import): the stores are the exchange"""
+        api.render_inplace_into(image_ptr, self.h, self.w, self.prepared, nframes=nbatch, frame_stride=frame_stride,
+                                max_depth=self.max_depth, part=part, nparts=nparts)
+
     def place(self, part, nparts, part_tensor, image):
         api.place_part(self.ctx, self.h, self.w, part, nparts, part_tensor.data_ptr(), image.data_ptr())
 
@@ -88,15 +94,31 @@ class ShardedStep:
 
     nbatch > 1: the step covers `nbatch` frames of EACH scene -- a renderer with a `.batch` method renders its
     nbatch frames in one launch (rt_render_batch), the single gather carries all of them, and `images[i]` is
-    an [nbatch, h, w] tensor."""
+    an [nbatch, h, w] tensor.
 
-    def __init__(self, frames, device, group=None, dst=0, nbatch=1):
+    exchange: "gather" -- the framebuffer gather described above (backend nccl: RCCL over xGMI), or "direct" -- NO gather:
+    rank dst owns the images in a buffer it exports to the other ranks (IPC mapping, rt_ipc_export / rt_ipc_import), and
+    every rank's kernel stores its pixels straight into them (rt_render_part_inplace) while it traces, over xGMI.  What is
+    left of the exchange is two one-element all-reduces per step: "the image may be overwritten" (dst has enqueued its
+    readers of the previous step's image; skipped with presync=False when the caller orders that itself) and "every rank's
+    stores have landed".  Needs renderers with an `.inplace` method and a `.ctx`; any rank failing to map the buffer puts
+    ALL ranks back on "gather" (`exchange_mode` says which one runs)."""
+
+    def __init__(self, frames, device, group=None, dst=0, nbatch=1, exchange="gather", presync=True):
         self.frames = list(frames)
         self.group, self.dst = group, dst
         self.nbatch = int(nbatch)
         self.device = torch.device(device)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.presync = bool(presync)
+        self.exchange_mode = "gather"
+        self.exchange_note = None
+        self._ipc_buf = None      # dst: the DeviceBuffer behind the images
+        self._ipc_base = None     # other ranks: the mapped pointer
+        if exchange == "direct" and (self.world > 1 or (dist.is_initialized() and os.environ.get("RT_FORCE_GATHER"))):
+            if self._setup_direct():
+                return
         self.pad_rows = [max_part_rows(h, self.world) for _, h, _ in self.frames]
         sizes = [self.nbatch * pr * w for pr, (_, _, w) in zip(self.pad_rows, self.frames)]
         self.offs = [int(o) for o in np.concatenate([[0], np.cumsum(sizes)])]   # int32 elements
@@ -127,11 +149,103 @@ class ShardedStep:
                 self.recv_all = torch.empty((self.world, self.total), dtype=torch.int32, device=self.device)
                 self.recv = [self.recv_all[p] for p in range(self.world)]
 
+    # ---- exchange = "direct": the images live on rank dst, every rank stores into them ----
+    def _setup_direct(self):
+        r0 = self.frames[0][0]
+        if not all(hasattr(fr[0], "inplace") and hasattr(fr[0], "ctx") for fr in self.frames):
+            self.exchange_note = "renderers without .inplace: gather"
+            return False
+        sizes = [self.nbatch * h * w for _, h, w in self.frames]
+        self.img_offs = [int(o) for o in np.concatenate([[0], np.cumsum(sizes)])]
+        handle, ok, err = None, 1, ""
+        try:
+            if self.rank == self.dst:
+                self._ipc_buf = r0.ctx.alloc_i32(self.img_offs[-1])
+                handle = api.ipc_export(r0.ctx, self._ipc_buf.ptr)
+            box = [handle]
+            dist.broadcast_object_list(box, src=self.dst, group=self.group)
+            if self.rank != self.dst:
+                self._ipc_base = api.ipc_import(r0.ctx, box[0])
+        except Exception as e:   # noqa: BLE001 -- whatever went wrong, every rank must learn of it
+            ok, err = 0, f"rank {self.rank}: {e}"
+        oks = [None] * self.world
+        dist.all_gather_object(oks, (ok, err), group=self.group)
+        if not all(o for o, _ in oks):
+            self.exchange_note = "direct stores unavailable (" + "; ".join(e for o, e in oks if not o) + "): gather"
+            self._release_direct()
+            return False
+        self.exchange_mode = "direct"
+        self.direct = False
+        self.host_staged = False
+        self.cpu_backend = dist.get_backend(self.group) == "gloo"
+        self.images = None
+        if self.rank == self.dst:
+            full = self._ipc_buf.as_torch((self.img_offs[-1],))
+            self.images = [full[self.img_offs[i]:self.img_offs[i + 1]].view((h, w) if self.nbatch == 1 else (self.nbatch, h, w))
+                           for i, (_, h, w) in enumerate(self.frames)]
+            self.send = full   # (what a caller poisons: the whole buffer)
+        else:
+            self.send = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device="cpu" if self.cpu_backend else self.device)
+        return True
+
+    def _release_direct(self):
+        try:
+            if self._ipc_base is not None:
+                api.ipc_close(self.frames[0][0].ctx, self._ipc_base)
+        except Exception:   # noqa: BLE001
+            pass
+        self._ipc_base = None
+        if self._ipc_buf is not None:
+            self._ipc_buf.free()
+        self._ipc_buf = None
+
+    def close(self):
+        """direct mode: unmap (other ranks) before the owner frees; collective"""
+        if self.exchange_mode != "direct":
+            return
+        self.images = None
+        torch.cuda.synchronize(self.device)
+        if self.rank != self.dst:
+            self._release_direct()
+        if dist.is_initialized():
+            dist.barrier(group=self.group)
+        self._release_direct()
+        self.exchange_mode = "closed"
+
+    def _signal(self):
+        """one element all-reduced on the current stream: behind it every rank's earlier work on ITS stream has completed
+        (gloo test mode: a host barrier behind a device sync)"""
+        if self.cpu_backend:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+        else:
+            dist.all_reduce(self.flag, group=self.group)
+
+    def _render_direct(self, events, gather_events):
+        if gather_events is not None:
+            gather_events[0].record()
+        if self.presync:
+            self._signal()          # rank dst's readers of the previous image are enqueued: it may be overwritten
+        base = self._ipc_buf.ptr if self.rank == self.dst else self._ipc_base
+        for i, (render_part, h, w) in enumerate(self.frames):
+            if events is not None and events[i] is not None:
+                events[i][0].record()
+            render_part.inplace(self.rank, self.world, self.nbatch, base + 4 * self.img_offs[i], h * w)
+            if events is not None and events[i] is not None:
+                events[i][1].record()
+        self._signal()              # every rank's stores have landed
+        if gather_events is not None:
+            gather_events[1].record()
+        return self.images
+
     def render(self, events=None, gather_events=None):
         """One step.  Returns the list of full image tensors on rank dst, None elsewhere.
         `events`: optional list (one per frame) of (start, end) torch.cuda.Event pairs recorded
         around this rank's kernel of that frame; `gather_events`: an optional (start, end) pair
         recorded around the exchange (gather + assembly on rank dst)."""
+        if self.exchange_mode == "direct":
+            return self._render_direct(events, gather_events)
         for i, (render_part, _, _) in enumerate(self.frames):
             if events is not None and events[i] is not None:
                 events[i][0].record()

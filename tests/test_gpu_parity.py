@@ -813,13 +813,16 @@ def test_batch_of_frames_in_one_launch(R, variant):
 
 
 # ---------------------------------------------------------------- one process, several devices ---
+@pytest.mark.parametrize("gather", [0, 1, 3])
 @pytest.mark.parametrize("scene,h,w", [("rgbbox", 333, 250), ("irreg", 1000, 1000)])
-def test_multi_device_context_on_one_gpu(R, scene, h, w):
+def test_multi_device_context_on_one_gpu(R, scene, h, w, gather):
     """rt_context_create_multi with the device listed three times: the whole fan-out (replicated prepare_scene,
-    cyclic row tiles on three streams, peer-copy gather, assembly) through the single-device entry points."""
+    cyclic row tiles on three streams, then either the devices' direct stores into the caller's image -- gather 3, and
+    what auto picks -- or the peer-copy gather + assembly) through the single-device entry points."""
     import bench
     mc = R.Context(devices=[0, 0, 0])
-    assert mc.num_devices == 3 and mc.gather_mode == "peer-copy"   # (a getter: no communicators are created for it)
+    mc.set_option("gather", gather)
+    assert mc.num_devices == 3 and mc.gather_mode == ("peer-copy" if gather == 1 else "direct-store")   # (a getter: no communicators are created for it)
     ps = R.prepare_scene(h, w, mc.scene(scene))
     want, _ = _oracle(scene).render(h, w)
     for rep in range(3):                       # frames chase each other through the shared gather buffers
@@ -845,8 +848,9 @@ def test_multi_device_context_on_one_gpu(R, scene, h, w):
     mc.close()
 
 
+@pytest.mark.parametrize("gather0", [1, 3])
 @pytest.mark.parametrize("scene,h,w,nb", [("irreg", 4000, 4000, 6), ("rgbbox", 333, 250, 5)])
-def test_batch_on_a_multi_device_context(R, scene, h, w, nb):
+def test_batch_on_a_multi_device_context(R, scene, h, w, nb, gather0):
     """rt_render_batch on a multi-device context (three parts on the one GPU): every device renders its row tiles of ALL the
     frames in one launch, one gather moves nframes x part per device, ONE assembly launch writes the images.  irreg
     4000x4000 is the configuration north_star states its scaling target on: six frames, each db269d43.  Then a camera
@@ -854,6 +858,7 @@ def test_batch_on_a_multi_device_context(R, scene, h, w, nb):
     import bench
     import torch
     mc = R.Context(devices=[0, 0, 0])
+    mc.set_option("gather", gather0)              # peer-copy gather + one assembly launch / direct stores into the images
     ps = R.prepare_scene(h, w, mc.scene(scene))
     buf = torch.empty((nb, h, w), dtype=torch.int32, device="cuda")
     want = bench.FRAME_CHECKSUM.get((scene, h, w))
@@ -877,7 +882,7 @@ def test_batch_on_a_multi_device_context(R, scene, h, w, nb):
     # a camera per frame, on the multi-device context and through the forced RCCL path of a single device
     orc = _oracle(scene)
     cams = np.stack([orc.camera_floats(h + 8 * f, w) for f in range(nb)])
-    for devices, gather in (([0, 0, 0], 0), ([0], 2)):
+    for devices, gather in (([0, 0, 0], gather0), ([0], 2)):
         mc = R.Context(devices=devices)
         mc.set_option("gather", gather)
         ps = R.prepare_scene(h, w, mc.scene(scene))
@@ -936,20 +941,22 @@ def test_multi_device_real_devices(R):
     import bench
     import torch
     mc = R.Context(devices=list(range(n)))
-    assert mc.gather_mode.startswith("rccl")           # (loaded at the first frame; falls back to peer copies if RCCL fails)
-    for scene, h, w in (("irreg", 4000, 4000), ("rgbbox", 1000, 1000)):
-        ps = R.prepare_scene(h, w, mc.scene(scene))
-        for rep in range(3):
-            assert O.checksum(R.render(h, w, ps)) == bench.FRAME_CHECKSUM[(scene, h, w)], rep
-        # ... and a batch: every device its rows of all six frames in one launch, one gather, one assembly launch
-        buf = torch.full((6, h, w), -1, dtype=torch.int32, device="cuda:0")
-        torch.cuda.synchronize()
-        R.render_batch_into(buf.data_ptr(), h, w, ps, 6, frame_stride=h * w)
-        mc.sync()
-        cks = bench.Checksummer(torch.device("cuda:0"))
-        assert all(cks(buf[f]) == bench.FRAME_CHECKSUM[(scene, h, w)] for f in range(6))
-        ps.free()
-    assert mc.gather_mode in ("rccl", "peer-copy")     # which of the two carried the frames (the report says why)
+    assert mc.gather_mode == "direct-store"            # auto: every device can store into the first one's memory
+    for gather in (3, 2, 1, 0):                        # direct stores over xGMI, RCCL send/recv, peer copies, auto
+        mc.set_option("gather", gather)
+        for scene, h, w in (("irreg", 4000, 4000), ("rgbbox", 1000, 1000)):
+            ps = R.prepare_scene(h, w, mc.scene(scene))
+            for rep in range(3):
+                assert O.checksum(R.render(h, w, ps)) == bench.FRAME_CHECKSUM[(scene, h, w)], (gather, rep)
+            # ... and a batch: every device its rows of all six frames in one launch (+ one gather, one assembly launch)
+            buf = torch.full((6, h, w), -1, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            R.render_batch_into(buf.data_ptr(), h, w, ps, 6, frame_stride=h * w)
+            mc.sync()
+            cks = bench.Checksummer(torch.device("cuda:0"))
+            assert all(cks(buf[f]) == bench.FRAME_CHECKSUM[(scene, h, w)] for f in range(6)), gather
+            ps.free()
+        assert mc.gather_mode in {3: ("direct-store",), 2: ("rccl", "peer-copy"), 1: ("peer-copy",), 0: ("direct-store",)}[gather]
     mc.close()
 
 
@@ -985,6 +992,116 @@ def test_reference_harness_unmodified_multi_device(devices, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     want, _ = _oracle("irreg").render(300, 400)
     assert int((_read_ppm(ppm) != want).sum()) == 0
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("scene,h,w", [("rgbbox", 77, 53), ("irreg", 200, 168)])
+def test_parts_rendered_in_place(R, ctx, scene, h, w, variant):
+    """rt_render_part_inplace: every part stores its rows at their places in ONE full image (what a rank does into rank 0's
+    buffer): all parts of 1, 2, 3 and 8 together give the oracle's image, a part alone leaves the other rows untouched;
+    a batch with a padded frame stride and a camera per frame; max_depth 0."""
+    import torch
+    ctx.set_variant(VARIANTS[variant])
+    ps = R.prepare_scene(h, w, ctx.scene(scene))
+    want, _ = _oracle(scene).render(h, w)
+    from raytracers_amd.dist import tile_rows
+    for nparts in (1, 2, 3, 8):
+        img = torch.full((h, w), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_inplace_into(img.data_ptr(), h, w, ps, part=nparts - 1, nparts=nparts)
+        ctx.sync()
+        got = img.cpu().numpy()
+        mine = tile_rows(h, nparts - 1, nparts)
+        other = np.setdiff1d(np.arange(h), mine)
+        assert (got[other] == -9).all() and int((got[mine] != want[mine]).sum()) == 0, nparts
+        for p in range(nparts - 1):
+            R.render_inplace_into(img.data_ptr(), h, w, ps, part=p, nparts=nparts)
+        ctx.sync()
+        assert int((img.cpu().numpy() != want).sum()) == 0, nparts
+    # a batch: three frames, padded stride, a camera each, parts 0..2 of 3
+    nb, stride = 3, h * w + 24
+    orc = _oracle(scene)
+    cams = np.stack([orc.camera_floats(h + 8 * f, w) for f in range(nb)])
+    buf = torch.full((nb, stride), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(3):
+        R.render_inplace_into(buf.data_ptr(), h, w, ps, nframes=nb, frame_stride=stride, cams=cams, part=p, nparts=3)
+    ctx.sync()
+    got = buf.cpu().numpy()
+    assert (got[:, h * w:] == -9).all()
+    for f in range(nb):
+        assert int((got[f, :h * w].reshape(h, w) != R.render_image(ps, w, h, cams[f])).sum()) == 0, f
+    # max_depth 0: black rows, only the part's own
+    img = torch.full((h, w), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    R.render_inplace_into(img.data_ptr(), h, w, ps, max_depth=0, part=1, nparts=2)
+    ctx.sync()
+    got = img.cpu().numpy()
+    mine = tile_rows(h, 1, 2)
+    assert (got[mine] == 0).all() and (np.delete(got, mine, axis=0) == -9).all()
+    ctx.set_variant(0)
+    ps.free()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_camera_batches_of_growing_size_on_one_context(R, devices):
+    """The camera block of rt_render_batch grows with the batch: a batch of 2 cameras, then of 20, then of 3 on the same
+    context (single-device, and a multi-device one where every child context stages its own copy)."""
+    import torch
+    mc = R.Context(devices=devices) if len(devices) > 1 else R.Context()
+    h, w = 64, 88
+    ps = R.prepare_scene(h, w, mc.irreg())
+    orc = _oracle("irreg")
+    for nb in (2, 20, 3):
+        cams = np.stack([orc.camera_floats(h + 8 * f, w) for f in range(nb)])
+        buf = torch.full((nb, h, w), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, nb, frame_stride=h * w, cams=cams)
+        mc.sync()
+        for f in (0, nb - 1):
+            assert int((buf[f].cpu().numpy() != R.render_image(ps, w, h, cams[f])).sum()) == 0, (nb, f)
+    ps.free()
+    mc.close()
+
+
+def test_render_entries_never_wait_for_the_device(R):
+    """Every rt_render* call after prepare_scene ENQUEUES and returns (include/rt_mi355x.h): with the stream kept busy by
+    a long launch, the calls that render a view for the second and third time -- where the view's deep-tile policy used
+    to be read back behind a stream synchronise -- come back while that launch is still running."""
+    import time
+    import torch
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = R.Context(0, st.cuda_stream)
+        big = R.prepare_scene(4000, 4000, ctx.irreg())
+        ps = R.prepare_scene(200, 200, ctx.irreg())
+        long_buf = torch.empty((8, 4000, 4000), dtype=torch.int32, device="cuda")
+        img = torch.empty((200, 200), dtype=torch.int32, device="cuda")
+        R.render_batch_into(long_buf.data_ptr(), 4000, 4000, big, 8, frame_stride=16000000)   # warm (tile order etc.)
+        R.render_into(img.data_ptr(), 200, 200, ps)
+        torch.cuda.synchronize()
+        ps2 = R.prepare_scene(200, 200, ctx.irreg())       # a prepared scene whose view has never been rendered
+        torch.cuda.synchronize()
+        busy = torch.cuda.Event()
+        R.render_batch_into(long_buf.data_ptr(), 4000, 4000, big, 8, frame_stride=16000000)   # ~15 ms of work on the stream
+        busy.record()
+        t0 = time.perf_counter()
+        for _ in range(4):                                  # first frame (records), second (used to sync), third, fourth
+            R.render_into(img.data_ptr(), 200, 200, ps2)
+        dt = time.perf_counter() - t0
+        still_running = not busy.query()
+        torch.cuda.synchronize()
+        want, _ = _oracle("irreg").render(200, 200)
+        assert int((img.cpu().numpy() != want).sum()) == 0
+        assert still_running, f"the four enqueues took {dt * 1e3:.2f} ms and the 8-frame launch ahead of them had already finished"
+        # ... and once the device has caught up the policy is there: the next frames run on it (same pixels)
+        for _ in range(2):
+            R.render_into(img.data_ptr(), 200, 200, ps2)
+            torch.cuda.synchronize()
+        assert int((img.cpu().numpy() != want).sum()) == 0
+        for p in (ps, ps2, big):
+            p.free()
+        ctx.close()
 
 
 # ---------------------------------------------------------------- error behaviour ---------
@@ -1073,17 +1190,49 @@ def test_bench_line_two_ranks_sharing_the_gpu():
     import sys
     env = dict(os.environ, RT_SHARE_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--exchange", "gather"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[:500]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "strong"
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "strong" and d["gather_mode"].startswith("gather")
     r = d["irreg_4000"]
     assert r["verified"] is True and r["ms_per_frame"] > 0 and r["Mray_s"] > 0
     assert r["render_us_per_rank"]["slowest"] >= r["render_us_per_rank"]["fastest"] > 0 and r["gather_and_assemble_us_rank0"] > 0
     assert r["batch"]["ms_per_frame"] > 0 and r["batch"]["frames_per_launch"] == r["frames"]
+
+
+def test_bench_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher, no WORLD_SIZE): bench.py re-executes itself under
+    torch.distributed.run with two ranks (here both on cuda:0, RT_SHARE_GPU=1) and the line says n_gpus == 2; the
+    framebuffer exchange is the direct-store one (rank 1 maps rank 0's image through the IPC entry points and stores its
+    rows into it), checked against the oracle's checksums before and after the timed region."""
+    import json
+    import sys
+    env = dict(os.environ, RT_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["gather_mode"].startswith("direct-store"), d["gather_mode"]
+    assert d["irreg_4000"]["verified"] is True
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """--gpus N with fewer than N devices is an error, not a smaller run under the wrong label."""
+    import sys
+    env = dict(os.environ)
+    env.pop("RT_SHARE_GPU", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and not out.stdout.strip()
+    assert "--gpus 64" in out.stderr
 
 
 def test_bench_refuses_wrong_pixels(tmp_path):
@@ -1148,9 +1297,23 @@ def _rank_worker(rank, world, port, scene, h, w, q):
         st = ShardedStep([(pr, h, w), (pr2, 77, 96)], device="cuda:0")
         for _ in range(2):
             imgs = st.render()
+        # the same step with the direct-store exchange: rank 0's image buffer mapped into the other processes (IPC), every
+        # rank's kernels store their rows into it; then a batch of three frames per scene the same way
+        sd = ShardedStep([(pr, h, w), (pr2, 77, 96)], device="cuda:0", exchange="direct")
+        assert sd.exchange_mode == "direct", sd.exchange_note
+        if rank == 0:
+            for im in sd.images:
+                im.fill_(-5)
+        for _ in range(2):
+            dimgs = sd.render()
+        sb = ShardedStep([(pr, h, w), (pr2, 77, 96)], device="cuda:0", exchange="direct", nbatch=3)
+        bimgs = sb.render()
         torch.cuda.synchronize()
         if rank == 0:
-            q.put((img.cpu().numpy().copy(), [i.cpu().numpy().copy() for i in imgs]))
+            assert all(bool((b[f] == d).all()) for b, d in zip(bimgs, dimgs) for f in range(3))
+            q.put((img.cpu().numpy().copy(), [i.cpu().numpy().copy() for i in imgs] + [i.cpu().numpy().copy() for i in dimgs]))
+        sb.close()
+        sd.close()
     finally:
         dist.destroy_process_group()
 
@@ -1177,3 +1340,4 @@ def test_multi_rank_render_sharing_one_gpu(world):
     assert int((step_imgs[0] != want).sum()) == 0
     want2, _ = _oracle("rgbbox").render(77, 96)
     assert int((step_imgs[1] != want2).sum()) == 0
+    assert int((step_imgs[2] != want).sum()) == 0 and int((step_imgs[3] != want2).sum()) == 0   # the direct-store exchange
