@@ -26,6 +26,14 @@
 #include "rt_device.hpp"
 #include "treelet.h"
 
+// tools/isa_budget.py compiles this file with -DRT_ISA_MARKS and counts the instructions between the marks (assembler
+// comments: no instruction, no effect on the product build, where the macro is empty)
+#ifdef RT_ISA_MARKS
+#define RT_MARK(name) asm volatile("; RT_MARK " name)
+#else
+#define RT_MARK(name)
+#endif
+
 namespace rtk {
 
 __device__ __forceinline__ int f2i(float f) { return __float_as_int(f); }
@@ -386,6 +394,75 @@ __device__ __forceinline__ float4 lds_load16(unsigned a) {
 }
 __device__ __forceinline__ unsigned lds_load4(unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(a); }
 
+// ---- quad-coalesced record fetch (WIDE instantiation of the pooled kernel) ----
+// A 64-byte node record fetched by ONE lane as four buffer_load_dwordx4 costs the L1 four tag look-ups (each instruction
+// presents 64 different lines); the same four instructions with lane p of every quad reading quarter p of the records of
+// the quad's four items present 16 lines each -- one look-up per record (profiles/r03/exp/pmc_mem_big.txt: 265 M L1
+// accesses per 10^6-sphere frame, 23.8 M of them missing).  The price is a 4 x 4 transpose inside the quad: two butterfly
+// stages of v_mov_dpp quad_perm + select per dword.
+template <int CTRL>
+__device__ __forceinline__ int quad_perm(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// One butterfly stage over eight register pairs (ra[k], rb[k]): lanes whose position bit is 0 keep ra and take the partner
+// lane's ra into rb; lanes whose bit is 1 keep rb and take the partner's rb into ra.  16 x v_cndmask_b32_dpp (the select
+// and the cross-lane move in ONE instruction -- hipcc makes three of `cond ? dpp(x) : y`), VCC = the lanes that keep.
+// (s_nop 1: a VGPR written by a VALU instruction must not be read through DPP within the next two wait states, and the
+// hazard recogniser does not look inside inline assembly.)
+#define RT_QT_STAGE(QP, LO, HI)                                                                                          \
+  asm volatile("s_nop 1\n\t"                                                                                             \
+               "s_mov_b32 vcc_lo, " LO "\n\ts_mov_b32 vcc_hi, " LO "\n\t"                                                \
+               "v_cndmask_b32_dpp %0, %8, %16, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
+               "v_cndmask_b32_dpp %1, %9, %17, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
+               "v_cndmask_b32_dpp %2, %10, %18, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_cndmask_b32_dpp %3, %11, %19, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_cndmask_b32_dpp %4, %12, %20, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_cndmask_b32_dpp %5, %13, %21, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_cndmask_b32_dpp %6, %14, %22, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_cndmask_b32_dpp %7, %15, %23, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "s_mov_b32 vcc_lo, " HI "\n\ts_mov_b32 vcc_hi, " HI "\n\t"                                                \
+               "v_cndmask_b32_dpp %8, %16, %8, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
+               "v_cndmask_b32_dpp %9, %17, %9, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
+               "v_cndmask_b32_dpp %10, %18, %10, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
+               "v_cndmask_b32_dpp %11, %19, %11, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
+               "v_cndmask_b32_dpp %12, %20, %12, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
+               "v_cndmask_b32_dpp %13, %21, %13, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
+               "v_cndmask_b32_dpp %14, %22, %14, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
+               "v_cndmask_b32_dpp %15, %23, %15, vcc " QP " row_mask:0xf bank_mask:0xf"                                    \
+               : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),  \
+                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7])   \
+               : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]), "v"(ra[7])           \
+               : "vcc")
+// (v_cndmask_b32_dpp D, S0, S1, vcc: D = vcc ? S1 : dpp(S0).  First group: t = keep-ra lanes ? ra : partner's rb;
+// second group: rb = keep-rb lanes ? rb : partner's ra.  ra is read only, t becomes the new ra.)
+__device__ __forceinline__ void quad_stage0(int (&ra)[8], int (&rb)[8]) {   // partner = lane ^ 1
+  int t[8];
+  RT_QT_STAGE("quad_perm:[1,0,3,2]", "0x55555555", "0xaaaaaaaa");
+  for (int k = 0; k < 8; ++k) ra[k] = t[k];
+}
+__device__ __forceinline__ void quad_stage1(int (&ra)[8], int (&rb)[8]) {   // partner = lane ^ 2
+  int t[8];
+  RT_QT_STAGE("quad_perm:[2,3,0,1]", "0x33333333", "0xcccccccc");
+  for (int k = 0; k < 8; ++k) ra[k] = t[k];
+}
+#undef RT_QT_STAGE
+// the record at byte offset `rec` (per lane) of the buffer, as its four quarters
+__device__ __forceinline__ void wide_fetch(__amdgpu_buffer_rsrc_t rsrc, int rec, int lane, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
+  const int pq16 = (lane & 3) << 4;
+  // a[j] = quarter (lane & 3) of the record of the quad's j-th item
+  const v4i a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0x00>(rec) + pq16, 0, 0);
+  const v4i a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0x55>(rec) + pq16, 0, 0);
+  const v4i a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0xAA>(rec) + pq16, 0, 0);
+  const v4i a3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0xFF>(rec) + pq16, 0, 0);
+  // element bit 0 <-> lane bit 0: pairs (a0, a1), (a2, a3); then element bit 1 <-> lane bit 1: pairs (a0, a2), (a1, a3)
+  int e0[8] = {a0.x, a0.y, a0.z, a0.w, a2.x, a2.y, a2.z, a2.w}, e1[8] = {a1.x, a1.y, a1.z, a1.w, a3.x, a3.y, a3.z, a3.w};
+  quad_stage0(e0, e1);   // e0 = {a0', a2'}, e1 = {a1', a3'}
+  int f0[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]}, f1[8] = {e0[4], e0[5], e0[6], e0[7], e1[4], e1[5], e1[6], e1[7]};
+  quad_stage1(f0, f1);   // f0 = {a0'', a1''}, f1 = {a2'', a3''}: quarter q of this lane's own record = a_q''
+  q0 = make_float4(__int_as_float(f0[0]), __int_as_float(f0[1]), __int_as_float(f0[2]), __int_as_float(f0[3]));
+  q1 = make_float4(__int_as_float(f0[4]), __int_as_float(f0[5]), __int_as_float(f0[6]), __int_as_float(f0[7]));
+  q2 = make_float4(__int_as_float(f1[0]), __int_as_float(f1[1]), __int_as_float(f1[2]), __int_as_float(f1[3]));
+  q3 = make_float4(__int_as_float(f1[4]), __int_as_float(f1[5]), __int_as_float(f1[6]), __int_as_float(f1[7]));
+}
+
 __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned smem_lds, unsigned wbase_lds, float ox, float oy, float oz,
                                                      float dx, float dy, float dz, float lr, float lg, float lb, int pix, int depth,
                                                      int ptile) {
@@ -513,7 +590,13 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO>
+// WIDE: nothing of the node array is staged in LDS (lds_nodes == 0) and BOX fetches its records quad-coalesced (wide_fetch).
+// COLD: the instantiation for the FIRST frame of a view (no exact tile order yet; the deep tiles are the ones a low-resolution
+// scout frame flagged, api.cpp: scout_view): a wave that finds itself carrying a ray of depth >= cold_hold_depth stops
+// refilling like a wave that drew a deep tile, and a wave that cannot refill (holding, or the queue is dry) and is left with
+// ONE live ray at a bounce boundary hands it to solo_trace from inside the loop -- the call costs this instantiation 4-7 %, which a frame that would
+// otherwise wait ~7 us per bounce for its longest chain gets back many times over.
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool WIDE = false, bool COLD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -586,6 +669,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   };
   unsigned q_state = queue_state_init((int)(blockIdx.x & ((1u << ns_log2) - 1u)), p.static_first != 0);
   bool q_enter = false;    // a ticket was drawn: (re)derive the tile's position
+  // COLD: the depth at which a wave turns to its long chain (never, when the scout flagged so many tiles that it said nothing)
+  const int cold_depth = COLD ? ((p.cold_info != nullptr && p.cold_info[1] != 0) ? 1 << 20 : p.cold_hold_depth) : 0;
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   unsigned long long tr_cyc[5] = {0, 0, 0, 0, 0}, tr_nt = 0, tr_nb2 = 0;   // shader cycles inside BOX / BOX2 / BOXT / LEAF / SHADE operations, treelet operations
@@ -634,6 +719,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     }
   }
   for (;;) {
+    RT_MARK("CHOICE_BEGIN");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
     // through uni(): hipcc's divergence analysis otherwise carries them in VGPRs and predicates
@@ -669,6 +755,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         } else {
           if (ns == 0) break;
           // ---- SHADE: finish completed folds, refill vacant slots, push the new roots ----
+          RT_MARK("SHADE_BEGIN");
           bool root = false;
           if (STATS) tr_ops[2]++;
           const unsigned long long tr_s0 = STATS ? clock64() : 0ull;
@@ -802,6 +889,25 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             pix = slot;
             root = true;
           }
+          if constexpr (COLD) {
+            const unsigned long long m_l = bal(pix >= 0);
+            if (!hold && bal(pix >= 0 && depth >= cold_depth) != 0ull) {   // a long chain nobody knew of: this wave serves it from now on
+              hold = true;
+              __builtin_amdgcn_s_setprio(3);
+            }
+            // (the lists are empty here -- SHADE runs behind the drained leaf list with nbox == 0 for a holding wave -- so the
+            // wave's LDS region is free for the solo loop)
+            if ((hold || exhausted) && nbox == 0 && m_l != 0ull && (m_l & (m_l - 1ull)) == 0ull && bal(root) == m_l && p.tl_log2 == kTreeletDepth) {
+              const int src = uni((int)__builtin_ctzll(m_l));
+              auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+              solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
+                         rl(r.oz), rl(r.dx), rl(r.dy), rl(r.dz), rl(lr), rl(lg), rl(lb), __builtin_amdgcn_readlane(pix, src),
+                         __builtin_amdgcn_readlane(depth, src), __builtin_amdgcn_readlane(ptile, src));
+              wkey[lane] = kKeyInit;     // (the solo loop used key 0 and the lists)
+              pix = -1;                  // the one live slot is done: its pixel is stored
+              root = false;
+            }
+          }
           // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
           if (root) ray_derive(r);   // one place for both scattered and primary rays
           const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
@@ -827,6 +933,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             else __builtin_amdgcn_s_setprio(0);
           }
           if (STATS) tr_cyc[4] += clock64() - tr_s0;
+          RT_MARK("SHADE_END");
           continue;
         }
       }
@@ -835,6 +942,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     }
     if (leaf_op) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
+      RT_MARK("LEAF_BEGIN");
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
       const unsigned long long tr_l0 = STATS ? clock64() : 0ull;
       const int top = nleaf - 1 - lane;
@@ -870,11 +978,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         atomicMin(&wkey[sl],
                   ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u));
       if (STATS) { __builtin_amdgcn_s_waitcnt(0); tr_cyc[3] += clock64() - tr_l0; }
+      RT_MARK("LEAF_END");
     } else {
       // ---- BOX: up to 64 (slot, node) items; each tests the boxes of BOTH children ----
       // (two instantiations: a FULL batch -- every lane has an item: no clamp, no activity mask -- and the general one)
       auto box = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        if constexpr (FULL) RT_MARK("BOXFULL_BEGIN"); else RT_MARK("BOXPART_BEGIN");
         if (STATS) { tr_ops[0]++; tr_items[0] += FULL ? 64 : nbox; }
         const int top = nbox - 1 - lane;
         const unsigned item = wbox[FULL ? top : (top < 0 ? 0 : top)];
@@ -888,7 +998,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
         q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
         float4 q0, q1, q2, q3;
-        {
+        if constexpr (WIDE) {
+          wide_fetch(rs_nodes, ni16 * 4, lane, q0, q1, q2, q3);   // (a lane without an item holds item 0: record 0, masked below)
+        } else {
           const int lo16 = ALL_LDS ? ni16 : (ni16 < 16 * plane ? ni16 : 0);
           const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
           q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
@@ -926,6 +1038,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         // touch the counter (same-address LDS atomics serialise): the ds_add runs under exactly their lane mask.
         const unsigned long long m_two = m_inl & m_inr, m_none = m_act & ~(m_inl | m_inr);
         lds_add_masked(m_two | m_none, (int)(size_t)wcnt + sl4, sel_mask(m_two, -1, 1));
+        if constexpr (FULL) RT_MARK("BOXFULL_END"); else RT_MARK("BOXPART_END");
       };
       // ---- BOX2: at most 32 items, TWO lanes and TWO tree levels each.  A wave with a nearly empty stack is on some
       // frame's critical path (a long bounce chain advances one operation per tree level): lane 2k handles the LEFT child
@@ -934,6 +1047,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
       // operations (a grandchild is tested iff its parent's box passed) for one operation's fixed latencies plus one LDS
       // round trip.
       auto box2 = [&]() {
+        RT_MARK("BOX2_BEGIN");
         if (STATS) { tr_ops[0]++; tr_items[0] += nbox; }
         const int role = lane & 1;
         const int top = nbox - 1 - (lane >> 1);
@@ -1004,6 +1118,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         // itself (counted once, by the pair's even lane)
         const int d = sel_mask(m_inl, 0, 1) + sel_mask(m_inr, 0, 1) - sel_mask(bal(act & (role == 0)), 0, 1);
         lds_add_masked(bal(d != 0), (int)(size_t)wcnt + sl4, d);
+        RT_MARK("BOX2_END");
       };
       const unsigned long long tr_b0 = STATS ? clock64() : 0ull;
       int tr_kind = 0;
@@ -1227,6 +1342,49 @@ __global__ __launch_bounds__(256) void place_all_kernel(const int32_t *stacked, 
 }
 
 // ---------------------------------------------------------------------------------
+// Scout of a new view (api.cpp: scout_view).  A view's first frame has no tile order, and its longest bounce chains start
+// wherever the raster order finds them.  Which tiles hold long chains is, however, visible in a frame a sixteenth of the
+// size with a bounce limit of 3: a pixel whose chain is still alive at the limit comes out BLACK (ray_colour returns
+// light * 0 when the budget is spent, ray.fut:136-147 -- every other chain ends in the sky colour), and long chains
+// cluster (irreg 1000x1000: the 8.5 % of the tiles under a black scout pixel hold every chain of >= 32 bounces and 99 % of
+// those of >= 16).  scout_flag_kernel gives a flagged tile the cost kScoutCost, scout_guard_kernel withdraws the flags when
+// they say nothing (rgbbox: 73 % of the tiles), and the ordinary tile_order sort turns them into the first frame's order.
+// The scout only permutes and groups independent pixels: the frame's pixels are the kernel's, bit for bit.
+// ---------------------------------------------------------------------------------
+constexpr int kScoutCost = 8;   // cost class of a flagged tile: chains of 8 .. 15 (deep_class 5 covers it)
+__global__ __launch_bounds__(256) void scout_flag_kernel(const int32_t *scout, int hs, int ws, int div, int tiles_x, int ntiles, int h, int w,
+                                                         int *cost, int *nflag) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  int flag = 0;
+  if (t < ntiles) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int r0 = (8 * ty) / div, r1 = min(hs - 1, (min(h - 1, 8 * ty + 7)) / div);
+    const int c0 = (8 * tx) / div, c1 = min(ws - 1, (min(w - 1, 8 * tx + 7)) / div);
+    for (int r = r0; r <= r1; ++r)
+      for (int c = c0; c <= c1; ++c) flag |= scout[(size_t)r * ws + c] == 0 ? 1 : 0;
+    cost[t] = flag ? kScoutCost : 0;
+  }
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(flag != 0);
+  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(nflag, (int)__popcll(m));
+}
+// more than one tile in `max_frac_inv` flagged: the scout does not discriminate -- no flags (and the host learns of it: info[1])
+__global__ __launch_bounds__(256) void scout_guard_kernel(int *cost, int ntiles, int *nflag, int max_frac_inv, int *info) {
+  const int n = *nflag;
+  const bool useless = (long long)n * max_frac_inv > (long long)ntiles;
+  if (useless)
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) cost[t] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) { info[0] = n; info[1] = useless ? 1 : 0; }
+}
+// (nflag: one int of device memory, zeroed here; info: two ints the host may read later, or nullptr)
+hipError_t launch_scout_flags(const int32_t *scout, int hs, int ws, int div, int tiles_x, int ntiles, int h, int w, int *cost, int *nflag,
+                              int max_frac_inv, int *info, hipStream_t stream) {
+  if (hipError_t e = hipMemsetAsync(nflag, 0, sizeof(int), stream); e != hipSuccess) return e;
+  hipLaunchKernelGGL(scout_flag_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, scout, hs, ws, div, tiles_x, ntiles, h, w, cost, nflag);
+  hipLaunchKernelGGL(scout_guard_kernel, dim3(min(64, (ntiles + 255) / 256)), dim3(256), 0, stream, cost, ntiles, nflag, max_frac_inv, info);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------
 hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream) {
@@ -1288,10 +1446,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, bool WIDE = false, bool COLD = false>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, WIDE, COLD>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1303,6 +1461,12 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
+  // (WIDE: the host sets p.wide only with lds_nodes == 0; workgroups of 16 waves only, no solo prologue)
+  if (p.wide && !all_lds && p.lds_nodes == 0 && waves_per_wg == 16) return launch_pooled_t<1024, false, false, false, true>(p, grid, stream);
+  // (COLD: a scouted first frame; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
+  if (p.cold_hold_depth > 0 && waves_per_wg == 16 && !solo)
+    return all_lds ? launch_pooled_t<1024, true, false, false, false, true>(p, grid, stream)
+                   : launch_pooled_t<1024, false, false, false, false, true>(p, grid, stream);
 #define RT_POOLED_CASE(W)                                                                                               \
   case W:                                                                                                               \
     return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \

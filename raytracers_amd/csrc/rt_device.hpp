@@ -192,6 +192,9 @@ struct KParams {
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
+  int cold_hold_depth;   // pooled family, COLD instantiation (a view's scouted first frame): a wave carrying a ray of this depth stops refilling (0: not a cold launch)
+  const int *cold_info;  // ... {flagged tiles, useless}: written by the scout's guard kernel ahead of this launch; useless != 0 switches the dynamic hold off
+  int wide;              // pooled family: quad-coalesced record fetch in BOX (the WIDE instantiation; needs lds_nodes == 0)
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)
@@ -231,6 +234,8 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, cha
 constexpr int kOrderBlocksMax = 64;                                   // workgroups per shard of the tile-order sort
 constexpr int kOrderScratchInts = kMaxShards * 64 * kOrderBlocksMax;   // its scratch: [shard][bin][workgroup] counts
 hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, int *scratch, hipStream_t stream);
+hipError_t launch_scout_flags(const int32_t *scout, int hs, int ws, int div, int tiles_x, int ntiles, int h, int w, int *cost, int *nflag,
+                              int max_frac_inv, int *info, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

@@ -151,6 +151,13 @@ def test_big_2000_at_size(R, ctx):
     assert (st["rays"], st["box_tests"], st["leaf_tests"]) == bench.FRAME_WORK[("big", 2000, 2000)] == \
         (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"])
     ps.free()
+    wc = R.Context()                      # the WIDE instantiation: no node prefix in LDS, quad-coalesced record fetches
+    wc.set_option("wide", 1)
+    ps = R.prepare_scene(2000, 2000, wc.scene("big"))
+    for rep in range(2):                  # unordered, then ordered
+        assert O.checksum(R.render(2000, 2000, ps)) == 0x3A198726, rep
+    ps.free()
+    wc.close()
     mc = R.Context(devices=[0, 0, 0])
     ps = R.prepare_scene(2000, 2000, mc.scene("big"))
     assert O.checksum(R.render(2000, 2000, ps)) == 0x3A198726
@@ -224,6 +231,67 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
         c.sync()
         assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch")
         ps.free()
+    c.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(scout=0), dict(cold_hold_depth=1), dict(cold_hold_depth=3, thr_shade=8), dict(cold_hold_depth=50),
+                                  dict(gpu_build=0), dict(box2=0, cold_hold_depth=2)])
+def test_scouted_first_frames(R, opts):
+    """A view's FIRST frame: the low-resolution scout frame, its flags as the frame's tile order, the COLD instantiation
+    (dynamic hold, hand-over of a wave's last ray to the solo loop from inside the loop) -- and the pixels of the frame
+    are the oracle's, on the scene the scout discriminates (irreg), on the one where its guard withdraws the flags (rgbbox),
+    on a random scene, at sizes on either side of the scout's range; every frame is a new view (fresh prepared scenes and
+    a camera path), into a poisoned buffer."""
+    import bench
+    import torch
+    c = R.Context()
+    for k, v in opts.items():
+        c.set_option(k, v)
+    cks = bench.Checksummer(torch.device("cuda"))
+    for scene, h, w in (("irreg", 1000, 1000), ("rgbbox", 1000, 1000), ("irreg", 500, 500), ("rgbbox", 360, 360), ("irreg", 1400, 1400)):
+        ps = R.prepare_scene(h, w, c.scene(scene))
+        img = torch.full((h, w), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_into(img.data_ptr(), h, w, ps)
+        c.sync()
+        if (scene, h, w) in bench.FRAME_CHECKSUM:
+            assert cks(img) == bench.FRAME_CHECKSUM[(scene, h, w)], (scene, h, w, opts)
+        else:
+            want, _ = _oracle(scene).render(h, w)
+            assert int((img.cpu().numpy() != want).sum()) == 0, (scene, h, w, opts)
+        first = img.clone()
+        for _ in range(2):                     # the view's second and third frame (exact order, then the policy)
+            img.fill_(0x5a5a5a5a)
+            R.render_into(img.data_ptr(), h, w, ps)
+            c.sync()
+            assert bool((img == first).all())
+        # a camera path, every view new
+        if h == 500:
+            orc = _oracle(scene)
+            for f in range(4):
+                cam = orc.camera_floats(h + 8 * f, w)
+                img.fill_(0x5a5a5a5a)
+                R.render_into(img.data_ptr(), h, w, ps, cam=cam)
+                c.sync()
+                one = img.clone()
+                c.set_option("scout", 0)
+                c.set_option("adaptive_order", 0)
+                img.fill_(0x5a5a5a5a)
+                R.render_into(img.data_ptr(), h, w, ps, cam=cam)
+                c.sync()
+                c.set_option("adaptive_order", 1)
+                c.set_option("scout", opts.get("scout", 1))
+                assert bool((img == one).all()), (scene, f)
+        ps.free()
+    rng = np.random.default_rng(11)
+    s = np.zeros((3000, 7), np.float32)
+    s[:, 0:3] = rng.uniform(-60, 60, (3000, 3)); s[:, 1] *= 0.1
+    s[:, 3:6] = rng.uniform(0.3, 1.0, (3000, 3)); s[:, 6] = rng.uniform(0.5, 3.0, 3000)
+    sc = (s, (5.0, 30.0, 90.0), (0.0, 0.0, 0.0), 55.0)
+    ps = R.prepare_scene(640, 640, c.scene_from_spheres(*sc))
+    want, _ = O.OracleScene("custom", spheres7=s, look_from=sc[1], look_at=sc[2], fov=sc[3]).render(640, 640)
+    assert int((R.render(640, 640, ps) != want).sum()) == 0
+    ps.free()
     c.close()
 
 
@@ -446,6 +514,7 @@ def test_work_counters_match_oracle(R, ctx, scene, h):
     dict(waves_per_wg=4, wgs_per_cu=4), dict(waves_per_wg=16, wgs_per_cu=1), dict(thr_shade=1, thr_leaf=1),
     dict(thr_shade=64, thr_leaf=64), dict(lmax=2), dict(lmax=16), dict(lds_scene_bytes=0),
     dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192),
+    dict(wide=1), dict(wide=1, box2=0), dict(wide=1, waves_per_wg=8),     # quad-coalesced record fetches (16-wave workgroups; ignored otherwise)
 ])
 @pytest.mark.parametrize("variant", [2, 3])
 def test_persistent_knobs_do_not_change_pixels(R, opts, variant):

@@ -64,7 +64,11 @@ while time.time() < t_end:
                  xcd_queues=int(rng.choice([-1, 0, 1, 2])), tpt_log2=int(rng.choice([-1, -1, 0, 1, 2, 3, 4])),
                  static_first=int(rng.choice([0, 1, 1])),
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
-                 treelet=int(rng.choice([2, 2, 2, 1, 4])))
+                 treelet=int(rng.choice([2, 2, 2, 1, 4])),
+                 # quad-coalesced record fetches (the WIDE instantiation: 16-wave workgroups, no node prefix in LDS)
+                 wide=int(rng.choice([0, 0, 1])),
+                 # a view's first frame: scout frame + COLD instantiation (dynamic hold depth)
+                 scout=int(rng.choice([0, 1, 1])), cold_hold_depth=int(rng.choice([1, 2, 4, 12, 12, 50])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):
@@ -106,6 +110,13 @@ while time.time() < t_end:
             if R.part_rows(h, p, nparts):
                 R.render_into(stacked[p].data_ptr(), h, w, ps, max_depth=md, part=p, nparts=nparts)
         R.place_parts(ctx, h, w, nparts, pad, stacked.data_ptr(), image.data_ptr())
+        ctx.sync()
+        ok &= int((image.cpu().numpy() != ref).sum()) == 0
+        # ... and stored in place (what a rank does into rank 0's image): no part buffers, no assembly
+        image.fill_(-1)
+        torch.cuda.synchronize()
+        for p in range(nparts):
+            R.render_inplace_into(image.data_ptr(), h, w, ps, max_depth=md, part=p, nparts=nparts)
         ctx.sync()
         ok &= int((image.cpu().numpy() != ref).sum()) == 0
     cases += 1

@@ -11,8 +11,12 @@ held against it.  Per world size W and workload:
            and rendezvous (the single-rank gather of tools/gather_probe.py costs that much without moving a byte far);
   step     render + gather + assemble (bench.py's bracket holds one gather per scene; the second scene's gather overlaps
            the first's assembly, not modelled: the figure is the conservative sum).
+  direct   the direct-store exchange (round 4; what bench.py uses when it works): render_inplace = the slowest rank's share
+           rendered IN PLACE into a full-size image (measured: the 4-byte pixel stores go where the assembled image has
+           them), floored by the part's bytes over one link at HALF its rate (small scattered stores are not bulk
+           copies), + two one-element all-reduces per launch at the same fixed 25 us each.  No gather, no assembly.
 
-usage: scale_prediction.py [K=20] > profiles/r03/scale_prediction.json"""
+usage: scale_prediction.py [K=20] > profiles/r04/scale_prediction.json"""
 import json
 import os
 import sys
@@ -26,6 +30,7 @@ from raytracers_amd.dist import HipPartRenderer, max_part_rows
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 LINK_GBS, FIXED_US = 153.0, 25.0
+STORE_EFF = 0.5      # direct stores: fraction of a link's bulk rate that 4-byte pixel stores (32-byte row segments at best) are assumed to reach
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 frames = [("rgbbox", 1000, 1000), ("irreg", 1000, 1000)]
@@ -82,6 +87,22 @@ for W in (1, 2, 4, 8):
     step_us = (render + gather + asm) / K
     rec["headline_1000"] = {"render_us_slowest_rank": render, "render_us_fastest_rank": min(shares), "gather_us_model": gather,
                             "assemble_us": asm, "us_per_step": step_us, "Mray_s": (RAYS["rgbbox"] + RAYS["irreg"]) / step_us}
+    # the same through the direct-store exchange: every part in place into full-size images
+    dshares = []
+    imgs = [torch.zeros((K, h, w), dtype=torch.int32, device=dev) for _, h, w in frames]
+    for p in range(W):
+        def run_d():
+            for pr, (_, h, w), t, st in zip(prs, frames, imgs, streams):
+                with torch.cuda.stream(st):
+                    pr.inplace(p, W, K, t.data_ptr(), h * w)
+        dshares.append(timed(run_d))
+    d_render = max(dshares)
+    d_floor = 0.0 if W == 1 else sum(K * max_part_rows(h, W) * w * 4 for _, h, w in frames) / (STORE_EFF * LINK_GBS * 1e3)
+    d_sig = 0.0 if W == 1 else 2 * 2 * FIXED_US       # two launches (scenes), two signals each
+    d_step = (max(d_render, d_floor) + d_sig) / K
+    rec["headline_1000_direct"] = {"render_inplace_us_slowest_rank": d_render, "store_floor_us_model": d_floor, "signals_us_model": d_sig,
+                                   "us_per_step": d_step, "Mray_s": (RAYS["rgbbox"] + RAYS["irreg"]) / d_step}
+    del imgs
     # ---- irreg 4000x4000: one frame at a time, and six frames in one batch launch
     one, six = [], []
     for p in range(W):
@@ -98,6 +119,20 @@ for W in (1, 2, 4, 8):
                                    "assemble_us": a1, "us_per_frame": max(one) + g1 + a1, "Mray_s": RAYS["irreg4000"] / (max(one) + g1 + a1)}
     rec["irreg_4000_batch_of_6"] = {"render_us_slowest_rank": max(six), "gather_us_model": g6, "assemble_us": a6,
                                     "us_per_frame": (max(six) + g6 + a6) / 6, "Mray_s": RAYS["irreg4000"] * 6 / (max(six) + g6 + a6)}
+    # ... and through the direct-store exchange
+    done, dsix = [], []
+    i6 = torch.zeros((6, 4000, 4000), dtype=torch.int32, device=dev)
+    for p in range(W):
+        done.append(timed(lambda: big.inplace(p, W, 1, i6.data_ptr(), 16000000), sync_each=True))
+        dsix.append(timed(lambda: big.inplace(p, W, 6, i6.data_ptr(), 16000000), reps=3, warm=2))
+    del i6
+    fl = 0.0 if W == 1 else pb / (STORE_EFF * LINK_GBS * 1e3)
+    sg = 0.0 if W == 1 else 2 * FIXED_US
+    rec["irreg_4000_one_frame_direct"] = {"render_inplace_us_slowest_rank": max(done), "store_floor_us_model": fl, "signals_us_model": sg,
+                                          "us_per_frame": max(max(done), fl) + sg, "Mray_s": RAYS["irreg4000"] / (max(max(done), fl) + sg)}
+    rec["irreg_4000_batch_of_6_direct"] = {"render_inplace_us_slowest_rank": max(dsix), "store_floor_us_model": 6 * fl, "signals_us_model": sg,
+                                           "us_per_frame": (max(max(dsix), 6 * fl) + sg) / 6,
+                                           "Mray_s": RAYS["irreg4000"] * 6 / (max(max(dsix), 6 * fl) + sg)}
     if W == 1:
         base = {k: (v.get("us_per_step") or v.get("us_per_frame")) for k, v in rec.items()}
     for k, v in rec.items():
