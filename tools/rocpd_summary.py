@@ -34,9 +34,17 @@ def main():
             tot = sum(sum(v) for v in dur.values())
             print("kernel-trace: name | calls | total_ns | mean_ns | min_ns | max_ns | % of GPU time"
                   + (f" | mean_ns of the last {last} dispatches" if last else ""))
+            queued = False
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
                 tail = f" | {sum(v[-last:]) / len(v[-last:]):.0f}" if last else ""
-                print(f"  {k[:90]} | {len(v)} | {sum(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | {100.0 * sum(v) / tot:.2f}{tail}")
+                # a small kernel whose longest dispatch is 50x its shortest did not run that long: it WAITED (see the note below)
+                mark = " [*]" if (max(v) > 50 * max(1, min(v)) and min(v) < 100000) else ""
+                queued |= bool(mark)
+                print(f"  {k[:90]}{mark} | {len(v)} | {sum(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} | {100.0 * sum(v) / tot:.2f}{tail}")
+            if queued:
+                print("  [*] the trace clocks a dispatch from the moment it is handed to the hardware: these dispatches sat behind another stream's "
+                      "persistent launch (every CU's LDS taken) for most of the time shown; min_ns is what the kernel takes alone, and its share of "
+                      "the GPU time is queueing, not work")
         cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         acc = collections.defaultdict(list)
         for f in cc:
