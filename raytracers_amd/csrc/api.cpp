@@ -206,10 +206,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   int budget = budget_of(shapes[static_cast<size_t>(pick)]);
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   int ln, ls;
-  if (pooled && ctx->wide) {      // WIDE: the node records come from L2 / HBM quad-coalesced; LDS keeps spheres only
-    ln = 0;
-    ls = std::min(n, budget / 16);
-  } else if (ctx->lds_sph_first) {
+  if (ctx->lds_sph_first) {
     ls = std::min(n, budget / 16);
     ln = std::min(ni, (budget - ls * 16) / node_bytes);
   } else {
@@ -460,7 +457,6 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
-  p.wide = ctx->wide && pl.lds_nodes == 0;
   p.tl_log2 = ps->tl_depth;
   p.solo = ctx->solo;
   if (pl.variant == RT_VARIANT_POOLED) {
@@ -521,7 +517,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // order the view does not have yet.  Whole frames of the policy's size range only, on the shapes the COLD kernel exists for.
       if (!to->valid && ctx->scout && ctx->adaptive_order == 1 && ctx->deep_class < 0 && nframes == 1 && nparts == 1 && !inplace &&
           order_shards == 1 && p.nchunks >= 2048 && p.nchunks <= 32768 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
-          ps->tl_depth == rtk::kTreeletDepth && ctx->grid_div == 0 && !ctx->wide) {
+          ps->tl_depth == rtk::kTreeletDepth && ctx->grid_div == 0) {
         if (int rc = scout_view(ctx, ps, to, h, w, cam12, p.tiles_x, &scouted)) return rc;
       }
       p.cost = rerecord ? to->cost : nullptr;
@@ -724,8 +720,6 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->scout = v != 0;
   } else if (k == "cold_hold_depth") {
     ctx->cold_hold_depth = std::max(1, std::min(64, v));
-  } else if (k == "wide") {
-    ctx->wide = v != 0;
   } else if (k == "solo") {
     ctx->solo = v != 0;
   } else if (k == "treelet") {

@@ -394,75 +394,6 @@ __device__ __forceinline__ float4 lds_load16(unsigned a) {
 }
 __device__ __forceinline__ unsigned lds_load4(unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(a); }
 
-// ---- quad-coalesced record fetch (WIDE instantiation of the pooled kernel) ----
-// A 64-byte node record fetched by ONE lane as four buffer_load_dwordx4 costs the L1 four tag look-ups (each instruction
-// presents 64 different lines); the same four instructions with lane p of every quad reading quarter p of the records of
-// the quad's four items present 16 lines each -- one look-up per record (profiles/r03/exp/pmc_mem_big.txt: 265 M L1
-// accesses per 10^6-sphere frame, 23.8 M of them missing).  The price is a 4 x 4 transpose inside the quad: two butterfly
-// stages of v_mov_dpp quad_perm + select per dword.
-template <int CTRL>
-__device__ __forceinline__ int quad_perm(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-// One butterfly stage over eight register pairs (ra[k], rb[k]): lanes whose position bit is 0 keep ra and take the partner
-// lane's ra into rb; lanes whose bit is 1 keep rb and take the partner's rb into ra.  16 x v_cndmask_b32_dpp (the select
-// and the cross-lane move in ONE instruction -- hipcc makes three of `cond ? dpp(x) : y`), VCC = the lanes that keep.
-// (s_nop 1: a VGPR written by a VALU instruction must not be read through DPP within the next two wait states, and the
-// hazard recogniser does not look inside inline assembly.)
-#define RT_QT_STAGE(QP, LO, HI)                                                                                          \
-  asm volatile("s_nop 1\n\t"                                                                                             \
-               "s_mov_b32 vcc_lo, " LO "\n\ts_mov_b32 vcc_hi, " LO "\n\t"                                                \
-               "v_cndmask_b32_dpp %0, %8, %16, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
-               "v_cndmask_b32_dpp %1, %9, %17, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
-               "v_cndmask_b32_dpp %2, %10, %18, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "v_cndmask_b32_dpp %3, %11, %19, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "v_cndmask_b32_dpp %4, %12, %20, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "v_cndmask_b32_dpp %5, %13, %21, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "v_cndmask_b32_dpp %6, %14, %22, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "v_cndmask_b32_dpp %7, %15, %23, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                               \
-               "s_mov_b32 vcc_lo, " HI "\n\ts_mov_b32 vcc_hi, " HI "\n\t"                                                \
-               "v_cndmask_b32_dpp %8, %16, %8, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
-               "v_cndmask_b32_dpp %9, %17, %9, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                                \
-               "v_cndmask_b32_dpp %10, %18, %10, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
-               "v_cndmask_b32_dpp %11, %19, %11, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
-               "v_cndmask_b32_dpp %12, %20, %12, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
-               "v_cndmask_b32_dpp %13, %21, %13, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
-               "v_cndmask_b32_dpp %14, %22, %14, vcc " QP " row_mask:0xf bank_mask:0xf\n\t"                              \
-               "v_cndmask_b32_dpp %15, %23, %15, vcc " QP " row_mask:0xf bank_mask:0xf"                                    \
-               : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),  \
-                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7])   \
-               : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]), "v"(ra[7])           \
-               : "vcc")
-// (v_cndmask_b32_dpp D, S0, S1, vcc: D = vcc ? S1 : dpp(S0).  First group: t = keep-ra lanes ? ra : partner's rb;
-// second group: rb = keep-rb lanes ? rb : partner's ra.  ra is read only, t becomes the new ra.)
-__device__ __forceinline__ void quad_stage0(int (&ra)[8], int (&rb)[8]) {   // partner = lane ^ 1
-  int t[8];
-  RT_QT_STAGE("quad_perm:[1,0,3,2]", "0x55555555", "0xaaaaaaaa");
-  for (int k = 0; k < 8; ++k) ra[k] = t[k];
-}
-__device__ __forceinline__ void quad_stage1(int (&ra)[8], int (&rb)[8]) {   // partner = lane ^ 2
-  int t[8];
-  RT_QT_STAGE("quad_perm:[2,3,0,1]", "0x33333333", "0xcccccccc");
-  for (int k = 0; k < 8; ++k) ra[k] = t[k];
-}
-#undef RT_QT_STAGE
-// the record at byte offset `rec` (per lane) of the buffer, as its four quarters
-__device__ __forceinline__ void wide_fetch(__amdgpu_buffer_rsrc_t rsrc, int rec, int lane, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
-  const int pq16 = (lane & 3) << 4;
-  // a[j] = quarter (lane & 3) of the record of the quad's j-th item
-  const v4i a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0x00>(rec) + pq16, 0, 0);
-  const v4i a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0x55>(rec) + pq16, 0, 0);
-  const v4i a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0xAA>(rec) + pq16, 0, 0);
-  const v4i a3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, quad_perm<0xFF>(rec) + pq16, 0, 0);
-  // element bit 0 <-> lane bit 0: pairs (a0, a1), (a2, a3); then element bit 1 <-> lane bit 1: pairs (a0, a2), (a1, a3)
-  int e0[8] = {a0.x, a0.y, a0.z, a0.w, a2.x, a2.y, a2.z, a2.w}, e1[8] = {a1.x, a1.y, a1.z, a1.w, a3.x, a3.y, a3.z, a3.w};
-  quad_stage0(e0, e1);   // e0 = {a0', a2'}, e1 = {a1', a3'}
-  int f0[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]}, f1[8] = {e0[4], e0[5], e0[6], e0[7], e1[4], e1[5], e1[6], e1[7]};
-  quad_stage1(f0, f1);   // f0 = {a0'', a1''}, f1 = {a2'', a3''}: quarter q of this lane's own record = a_q''
-  q0 = make_float4(__int_as_float(f0[0]), __int_as_float(f0[1]), __int_as_float(f0[2]), __int_as_float(f0[3]));
-  q1 = make_float4(__int_as_float(f0[4]), __int_as_float(f0[5]), __int_as_float(f0[6]), __int_as_float(f0[7]));
-  q2 = make_float4(__int_as_float(f1[0]), __int_as_float(f1[1]), __int_as_float(f1[2]), __int_as_float(f1[3]));
-  q3 = make_float4(__int_as_float(f1[4]), __int_as_float(f1[5]), __int_as_float(f1[6]), __int_as_float(f1[7]));
-}
-
 __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned smem_lds, unsigned wbase_lds, float ox, float oy, float oz,
                                                      float dx, float dy, float dz, float lr, float lg, float lb, int pix, int depth,
                                                      int ptile) {
@@ -590,13 +521,12 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
-// WIDE: nothing of the node array is staged in LDS (lds_nodes == 0) and BOX fetches its records quad-coalesced (wide_fetch).
 // COLD: the instantiation for the FIRST frame of a view (no exact tile order yet; the deep tiles are the ones a low-resolution
 // scout frame flagged, api.cpp: scout_view): a wave that finds itself carrying a ray of depth >= cold_hold_depth stops
 // refilling like a wave that drew a deep tile, and a wave that cannot refill (holding, or the queue is dry) and is left with
 // ONE live ray at a bounce boundary hands it to solo_trace from inside the loop -- the call costs this instantiation 4-7 %, which a frame that would
 // otherwise wait ~7 us per bounce for its longest chain gets back many times over.
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool WIDE = false, bool COLD = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool COLD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -998,9 +928,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         q.ox = ra.x; q.oy = ra.y; q.oz = ra.z;
         q.ix = ri.x; q.iy = ri.y; q.iz = ri.z;
         float4 q0, q1, q2, q3;
-        if constexpr (WIDE) {
-          wide_fetch(rs_nodes, ni16 * 4, lane, q0, q1, q2, q3);   // (a lane without an item holds item 0: record 0, masked below)
-        } else {
+        {
           const int lo16 = ALL_LDS ? ni16 : (ni16 < 16 * plane ? ni16 : 0);
           const float4 *const np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(smem) + lo16);
           q0 = np[0]; q1 = np[plane]; q2 = np[2 * plane]; q3 = np[3 * plane];
@@ -1446,10 +1374,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, bool WIDE = false, bool COLD = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, bool COLD = false>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, WIDE, COLD>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, COLD>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1461,12 +1389,10 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
-  // (WIDE: the host sets p.wide only with lds_nodes == 0; workgroups of 16 waves only, no solo prologue)
-  if (p.wide && !all_lds && p.lds_nodes == 0 && waves_per_wg == 16) return launch_pooled_t<1024, false, false, false, true>(p, grid, stream);
   // (COLD: a scouted first frame; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
   if (p.cold_hold_depth > 0 && waves_per_wg == 16 && !solo)
-    return all_lds ? launch_pooled_t<1024, true, false, false, false, true>(p, grid, stream)
-                   : launch_pooled_t<1024, false, false, false, false, true>(p, grid, stream);
+    return all_lds ? launch_pooled_t<1024, true, false, false, true>(p, grid, stream)
+                   : launch_pooled_t<1024, false, false, false, true>(p, grid, stream);
 #define RT_POOLED_CASE(W)                                                                                               \
   case W:                                                                                                               \
     return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \

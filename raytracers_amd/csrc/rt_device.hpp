@@ -194,7 +194,6 @@ struct KParams {
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int cold_hold_depth;   // pooled family, COLD instantiation (a view's scouted first frame): a wave carrying a ray of this depth stops refilling (0: not a cold launch)
   const int *cold_info;  // ... {flagged tiles, useless}: written by the scout's guard kernel ahead of this launch; useless != 0 switches the dynamic hold off
-  int wide;              // pooled family: quad-coalesced record fetch in BOX (the WIDE instantiation; needs lds_nodes == 0)
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)

@@ -39,7 +39,6 @@ struct rt_context {
   int32_t *scout_buf = nullptr;   // the scout frame (device), grown on demand
   size_t scout_elems = 0;
   int *scout_ctr = nullptr;       // device: flagged-tile counter, then {flagged, useless} for the host
-  int wide = 0;             // pooled family: 1 = no node prefix in LDS and quad-coalesced record fetches in BOX (the WIDE instantiation, 16-wave workgroups)
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
   int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)

@@ -151,13 +151,6 @@ def test_big_2000_at_size(R, ctx):
     assert (st["rays"], st["box_tests"], st["leaf_tests"]) == bench.FRAME_WORK[("big", 2000, 2000)] == \
         (cnt["rays"], cnt["box_tests"], cnt["leaf_tests"])
     ps.free()
-    wc = R.Context()                      # the WIDE instantiation: no node prefix in LDS, quad-coalesced record fetches
-    wc.set_option("wide", 1)
-    ps = R.prepare_scene(2000, 2000, wc.scene("big"))
-    for rep in range(2):                  # unordered, then ordered
-        assert O.checksum(R.render(2000, 2000, ps)) == 0x3A198726, rep
-    ps.free()
-    wc.close()
     mc = R.Context(devices=[0, 0, 0])
     ps = R.prepare_scene(2000, 2000, mc.scene("big"))
     assert O.checksum(R.render(2000, 2000, ps)) == 0x3A198726
@@ -514,7 +507,6 @@ def test_work_counters_match_oracle(R, ctx, scene, h):
     dict(waves_per_wg=4, wgs_per_cu=4), dict(waves_per_wg=16, wgs_per_cu=1), dict(thr_shade=1, thr_leaf=1),
     dict(thr_shade=64, thr_leaf=64), dict(lmax=2), dict(lmax=16), dict(lds_scene_bytes=0),
     dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192),
-    dict(wide=1), dict(wide=1, box2=0), dict(wide=1, waves_per_wg=8),     # quad-coalesced record fetches (16-wave workgroups; ignored otherwise)
 ])
 @pytest.mark.parametrize("variant", [2, 3])
 def test_persistent_knobs_do_not_change_pixels(R, opts, variant):

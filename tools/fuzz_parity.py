@@ -65,8 +65,6 @@ while time.time() < t_end:
                  static_first=int(rng.choice([0, 1, 1])),
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
                  treelet=int(rng.choice([2, 2, 2, 1, 4])),
-                 # quad-coalesced record fetches (the WIDE instantiation: 16-wave workgroups, no node prefix in LDS)
-                 wide=int(rng.choice([0, 0, 1])),
                  # a view's first frame: scout frame + COLD instantiation (dynamic hold depth)
                  scout=int(rng.choice([0, 1, 1])), cold_hold_depth=int(rng.choice([1, 2, 4, 12, 12, 50])))
     for k, v in knobs.items():
