@@ -289,7 +289,7 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
   to->classes_pending = false;
   if (ctx->deep_class >= 0 || to->nshards != 1) return 0;   // no policy reads the table
   if (!ps->classes_pinned)
-    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * (kClassSlotInts * kClassSlots + 4), hipHostMallocDefault));
+    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * kClassSlotInts * kClassSlots, hipHostMallocDefault));
   if (to->classes_slot < 0) {
     unsigned used = 0;
     for (const auto &o : ps->orders)
@@ -303,50 +303,6 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
                              hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipEventRecord(to->classes_event, ctx->stream));
   to->classes_pending = true;
-  return 0;
-}
-
-// The scout of a new view (render_kernels.hip: scout_flag_kernel): a frame of a sixteenth of the pixels with a bounce limit of
-// 3 through the view's own camera, its black pixels -> flagged tiles -> the view's first tile order.  Everything is enqueued on
-// the context's stream; *scouted says whether `to->order` will hold a usable table when the frame's launch runs.
-int scout_view(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to, int64_t h, int64_t w, const float *cam12, int tiles_x, bool *scouted) {
-  rt_prepared *ps = const_cast<rt_prepared *>(ps_c);
-  *scouted = false;
-  if (ps->scout_pending && hipEventQuery(ps->scout_event) == hipSuccess) {   // an earlier scout's verdict has arrived
-    ps->scout_pending = false;
-    ps->scout_useless = ps->classes_pinned[kClassSlotInts * kClassSlots + 1];
-  }
-  (void)hipGetLastError();
-  if (ps->scout_useless) return 0;
-  constexpr int kDiv = 4, kBounces = 3, kMaxFracInv = 6;   // flags on more than a sixth of the tiles say nothing
-  const int64_t hs = (h + kDiv - 1) / kDiv, ws = (w + kDiv - 1) / kDiv;
-  if (static_cast<size_t>(hs * ws) > ctx->scout_elems) {
-    if (ctx->scout_buf) {
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      (void)hipFree(ctx->scout_buf);
-      ctx->scout_buf = nullptr;
-      ctx->scout_elems = 0;
-    }
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scout_buf), sizeof(int32_t) * static_cast<size_t>(hs * ws)));
-    ctx->scout_elems = static_cast<size_t>(hs * ws);
-  }
-  if (!ctx->scout_ctr) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scout_ctr), sizeof(int) * 4));
-  if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
-  if (!ps->classes_pinned)
-    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * (kClassSlotInts * kClassSlots + 4), hipHostMallocDefault));
-  if (!ps->scout_event) RT_HIP(ctx, hipEventCreateWithFlags(&ps->scout_event, hipEventDisableTiming));
-  ctx->in_scout = true;
-  const int rc = rti::enqueue_render(ctx, ps, hs, ws, kBounces, 8, 0, 1, ctx->scout_buf, false, cam12);
-  ctx->in_scout = false;
-  if (rc) return rc;
-  RT_HIP(ctx, rtk::launch_scout_flags(ctx->scout_buf, static_cast<int>(hs), static_cast<int>(ws), kDiv, tiles_x, to->ntiles, static_cast<int>(h),
-                                      static_cast<int>(w), to->cost, ctx->scout_ctr, kMaxFracInv, ctx->scout_ctr + 1, ctx->stream));
-  RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
-  RT_HIP(ctx, hipMemcpyAsync(ps->classes_pinned + kClassSlotInts * kClassSlots, ctx->scout_ctr + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
-  RT_HIP(ctx, hipEventRecord(ps->scout_event, ctx->stream));
-  ps->scout_pending = true;
-  ps->scouts++;
-  *scouted = true;
   return 0;
 }
 
@@ -464,8 +420,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
     TileOrder *to = nullptr;
-    bool scouted = false;
-    if (ctx->adaptive_order && !p.cams && !ctx->in_scout) {   // (a batch with its own cameras has no single view to order tiles by)
+    if (ctx->adaptive_order && !p.cams) {   // (a batch with its own cameras has no single view to order tiles by)
       for (auto &o : ps->orders)
         if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
             o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks &&
@@ -513,22 +468,43 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
       // recomputes every frame (testing aid).
       const bool rerecord = !to->valid || ctx->adaptive_order == 2;
-      // A view's FIRST frame: a scout frame first (a sixteenth of the pixels, three bounces) whose flags stand in for the
-      // order the view does not have yet.  Whole frames of the policy's size range only, on the shapes the COLD kernel exists for.
-      if (!to->valid && ctx->scout && ctx->adaptive_order == 1 && ctx->deep_class < 0 && nframes == 1 && nparts == 1 && !inplace &&
-          order_shards == 1 && p.nchunks >= 2048 && p.nchunks <= 32768 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
-          ps->tl_depth == rtk::kTreeletDepth && ctx->grid_div == 0) {
-        if (int rc = scout_view(ctx, ps, to, h, w, cam12, p.tiles_x, &scouted)) return rc;
-      }
       p.cost = rerecord ? to->cost : nullptr;
-      p.order = (to->valid || scouted) ? to->order : nullptr;
+      p.order = to->valid ? to->order : nullptr;
       DeepPolicy dp;
       if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
-      if (scouted) {
-        // the scout's flagged tiles (cost class "8 .. 15") are the deep ones: quarters first, to every wave that can take one; whole grid
-        dp = DeepPolicy{5, 2, 0, true};
-        p.cold_hold_depth = ctx->cold_hold_depth;
-        p.cold_info = ctx->scout_ctr + 1;
+      // A view's FIRST frame (no order yet): the COLD instantiation -- scout tiles at the head of the queue, a hot list for the
+      // tiles they flag, dynamic hold, in-loop hand-over to the solo loop (render_kernels.hip).  Whole single frames of the
+      // policy's size range, on the launch shape the instantiation exists for.
+      if (!to->valid && ctx->scout && ctx->adaptive_order == 1 && ctx->deep_class < 0 && nframes == 1 && nparts == 1 && !inplace &&
+          p.nshards > 0 && (p.nshards == 1 || p.interleave) && p.tpt_log2 == 0 && p.nchunks >= 2048 && p.nchunks <= 32768 && max_depth > 4 &&
+          pl.waves == 16 && ctx->solo && ps->tl_depth == rtk::kTreeletDepth && ctx->grid_div == 0) {
+        constexpr int kDiv = 4, kBounces = 3;
+        const int hs = static_cast<int>((h + kDiv - 1) / kDiv), ws = static_cast<int>((w + kDiv - 1) / kDiv);
+        const int stx = (ws + 7) / 8, nscout = stx * ((hs + 7) / 8);
+        if (nscout <= pl.grid_full * pl.waves && nscout < 65536) {   // every scout tile is some wave's first (static) ticket
+          // one device block: the word (its own 256 bytes), claim[ntiles], hot[4 * ntiles]; all zero at launch
+          const size_t bytes = 256 + sizeof(int) * 5 * static_cast<size_t>(p.nchunks);
+          if (bytes > ctx->cold_bytes) {
+            if (ctx->cold_buf) {
+              RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+              (void)hipFree(ctx->cold_buf);
+              ctx->cold_buf = nullptr;
+              ctx->cold_bytes = 0;
+            }
+            RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cold_buf), bytes));
+            ctx->cold_bytes = bytes;
+          }
+          RT_HIP(ctx, hipMemsetAsync(ctx->cold_buf, 0, bytes, ctx->stream));
+          p.cold_word = reinterpret_cast<unsigned long long *>(ctx->cold_buf);
+          p.cold_claim = reinterpret_cast<int *>(ctx->cold_buf + 256);
+          p.cold_hot = p.cold_claim + p.nchunks;
+          p.cold_nscout = nscout; p.cold_stx = stx; p.cold_hs = hs; p.cold_ws = ws;
+          p.cold_div = kDiv; p.cold_bounces = kBounces;
+          p.cold_limit = std::max(1, pl.grid_full * pl.waves / 4);
+          p.cold_hold_depth = ctx->cold_hold_depth;
+          p.cold_poll_cap = 1 << 16;
+          dp.sparse = true;   // every workgroup
+        }
       }
       p.deep_class = dp.deep_class;
       p.deep_split = dp.deep_split;
@@ -543,6 +519,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       }
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+    if (p.cold_word && std::getenv("RT_COLD_DEBUG")) {   // (diagnostic: the hot list's word after the frame)
+      unsigned long long wd = 0;
+      unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(&wd, p.cold_word, 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(dbg, reinterpret_cast<char *>(p.cold_word) + 64, sizeof dbg, hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "  counters (RT_COLD_COUNTERS builds): looks %u, took an entry %u, holding a reservation %u, saw the end %u; dry passes %u, cap exits %u, end exits %u\n",
+                   dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+      std::fprintf(stderr, "cold frame %dx%d: nscout %d, limit %d tiles; word: appended %llu, taken %llu, scout tiles finished %llu\n", p.w, p.h,
+                   p.cold_nscout, p.cold_limit, wd & 0xffffffull, (wd >> 24) & 0xffffffull, wd >> 48);
+    }
     if (to && p.cost) {
       // next frames' ticket -> tile table from this frame's record (also clears the record)
       if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
@@ -631,8 +618,7 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
-  if (ctx->scout_buf) (void)hipFree(ctx->scout_buf);
-  if (ctx->scout_ctr) (void)hipFree(ctx->scout_ctr);
+  if (ctx->cold_buf) (void)hipFree(ctx->cold_buf);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   if (ctx->arena) (void)hipFree(ctx->arena);
@@ -937,7 +923,6 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
     if (o.classes_event) (void)hipEventDestroy(o.classes_event);
   }
   if (ps->classes_pinned) (void)hipHostFree(ps->classes_pinned);
-  if (ps->scout_event) (void)hipEventDestroy(ps->scout_event);
   delete ps;
   return 0;
 }

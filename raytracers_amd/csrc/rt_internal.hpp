@@ -33,12 +33,10 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
-  int scout = 1;            // pooled family: the FIRST frame of a view is preceded by a low-resolution scout frame whose black pixels say which tiles hold long bounce chains (api.cpp: scout_view; 0: off)
-  int cold_hold_depth = 12; // ... and rendered by the COLD instantiation: a wave carrying a ray of this depth stops refilling
-  bool in_scout = false;    // (the scout launch itself is being enqueued: no tile order, no cost record for it)
-  int32_t *scout_buf = nullptr;   // the scout frame (device), grown on demand
-  size_t scout_elems = 0;
-  int *scout_ctr = nullptr;       // device: flagged-tile counter, then {flagged, useless} for the host
+  int scout = 1;            // pooled family: the FIRST frame of a view is rendered by the COLD instantiation (scout tiles + hot list, render_kernels.hip; 0: the ordinary kernel in raster order)
+  int cold_hold_depth = 12; // ... in which a wave carrying a ray of this depth stops refilling
+  char *cold_buf = nullptr; // its device block: the hot list's word, the tiles' owners, the hot list (grown on demand, zeroed per cold launch)
+  size_t cold_bytes = 0;
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
   int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)
@@ -135,11 +133,7 @@ struct rt_prepared {
   char *block = nullptr;   // one device allocation behind all of the arrays above
   size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-  int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables (allocated with the first ordered view), then 4 ints for the scout's verdict
-  hipEvent_t scout_event = nullptr;  // the last scout's {flagged tiles, useless} have landed in classes_pinned's tail
-  bool scout_pending = false;
-  int scout_useless = 0;             // a scout of this scene flagged so many tiles that it said nothing (rgbbox: 73 %): later new views skip it
-  int scouts = 0;                    // scout frames rendered for this prepared scene
+  int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables (allocated with the first ordered view)
   std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
   std::vector<std::future<int>> replica_jobs;   // ... while they are being built (rt_prepare_scene joins them)
 };

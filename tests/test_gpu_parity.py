@@ -228,13 +228,16 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(scout=0), dict(cold_hold_depth=1), dict(cold_hold_depth=3, thr_shade=8), dict(cold_hold_depth=50),
-                                  dict(gpu_build=0), dict(box2=0, cold_hold_depth=2)])
+                                  dict(gpu_build=0), dict(box2=0, cold_hold_depth=2), dict(static_first=0), dict(xcd_queues=0),
+                                  dict(xcd_queues=0, static_first=0, thr_shade=64), dict(xcd_queues=1)])
 def test_scouted_first_frames(R, opts):
-    """A view's FIRST frame: the low-resolution scout frame, its flags as the frame's tile order, the COLD instantiation
-    (dynamic hold, hand-over of a wave's last ray to the solo loop from inside the loop) -- and the pixels of the frame
-    are the oracle's, on the scene the scout discriminates (irreg), on the one where its guard withdraws the flags (rgbbox),
-    on a random scene, at sizes on either side of the scout's range; every frame is a new view (fresh prepared scenes and
-    a camera path), into a poisoned buffer."""
+    """A view's FIRST frame through the COLD instantiation: scout tiles at the head of the queue, the hot list of the tiles
+    they flag (every tile rendered exactly once: by the raster ticket that reached it first or through the hot list, in
+    quarters), dynamic hold, hand-over of a wave's last ray to the solo loop from inside the loop -- and the pixels of the
+    frame are the oracle's, on the scene where the scouts discriminate (irreg), on the one where they flag most tiles
+    (rgbbox: the hot list fills up to its limit), on a random scene, at sizes on either side of the range; every frame is a
+    new view (fresh prepared scenes and a camera path), into a poisoned buffer; scout tiles as static first tickets and drawn
+    from the counters, one ticket counter and eight."""
     import bench
     import torch
     c = R.Context()

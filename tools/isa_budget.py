@@ -79,6 +79,11 @@ def main():
             if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
                 continue
             acc[classify(t.split()[0])] += 1
+            # LEAF's body ends where it jumps back to the loop's head; what follows in layout order is code of OTHER operations
+            # that the compiler moved out of line (SHADE's refill, the ticket draw)
+            if cur == "LEAF_BEGIN" and t.split()[0] == "s_branch":
+                ranges.append((cur, acc))
+                cur, acc = "(out of line: SHADE's cold blocks -- refill, ticket draw, re-intersection)", collections.Counter()
         ranges.append((cur, acc))
         cols = ["VALU fp32 add/mul/fma", "VALU select/min/max/cmp", "VALU int/mov/other", "VALU cross-lane", "VALU div/sqrt/rcp", "SALU", "LDS",
                 "VMEM", "SMEM", "branch", "wait/nop"]
