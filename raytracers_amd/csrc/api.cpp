@@ -472,39 +472,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.order = to->valid ? to->order : nullptr;
       DeepPolicy dp;
       if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
-      // A view's FIRST frame (no order yet): the COLD instantiation -- scout tiles at the head of the queue, a hot list for the
-      // tiles they flag, dynamic hold, in-loop hand-over to the solo loop (render_kernels.hip).  Whole single frames of the
-      // policy's size range, on the launch shape the instantiation exists for.
-      if (!to->valid && ctx->scout && ctx->adaptive_order == 1 && ctx->deep_class < 0 && nframes == 1 && nparts == 1 && !inplace &&
-          p.nshards > 0 && (p.nshards == 1 || p.interleave) && p.tpt_log2 == 0 && p.nchunks >= 2048 && p.nchunks <= 32768 && max_depth > 4 &&
-          pl.waves == 16 && ctx->solo && ps->tl_depth == rtk::kTreeletDepth && ctx->grid_div == 0) {
-        constexpr int kDiv = 4, kBounces = 3;
-        const int hs = static_cast<int>((h + kDiv - 1) / kDiv), ws = static_cast<int>((w + kDiv - 1) / kDiv);
-        const int stx = (ws + 7) / 8, nscout = stx * ((hs + 7) / 8);
-        if (nscout <= pl.grid_full * pl.waves && nscout < 65536) {   // every scout tile is some wave's first (static) ticket
-          // one device block: the word (its own 256 bytes), claim[ntiles], hot[4 * ntiles]; all zero at launch
-          const size_t bytes = 256 + sizeof(int) * 5 * static_cast<size_t>(p.nchunks);
-          if (bytes > ctx->cold_bytes) {
-            if (ctx->cold_buf) {
-              RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-              (void)hipFree(ctx->cold_buf);
-              ctx->cold_buf = nullptr;
-              ctx->cold_bytes = 0;
-            }
-            RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cold_buf), bytes));
-            ctx->cold_bytes = bytes;
-          }
-          RT_HIP(ctx, hipMemsetAsync(ctx->cold_buf, 0, bytes, ctx->stream));
-          p.cold_word = reinterpret_cast<unsigned long long *>(ctx->cold_buf);
-          p.cold_claim = reinterpret_cast<int *>(ctx->cold_buf + 256);
-          p.cold_hot = p.cold_claim + p.nchunks;
-          p.cold_nscout = nscout; p.cold_stx = stx; p.cold_hs = hs; p.cold_ws = ws;
-          p.cold_div = kDiv; p.cold_bounces = kBounces;
-          p.cold_limit = std::max(1, pl.grid_full * pl.waves / 4);
-          p.cold_hold_depth = ctx->cold_hold_depth;
-          p.cold_poll_cap = 1 << 16;
-          dp.sparse = true;   // every workgroup
-        }
+      // A view's FIRST frame (no order yet): every workgroup -- the half-size launch that serves a partly LDS-resident scene's
+      // ordered frames best lets an unordered one wait for its late chains with half the chip (irreg, first frame: 700 x 700
+      // 0.605 -> 0.545 ms, 1000 x 1000 0.714 -> 0.625, 1400 x 1400 0.909 -> 0.738) -- and, up to ~800 x 800 pixels, the
+      // COLD instantiation (profiles/r04/exp/e7_first_frames_full_grid_vs_cold.txt).
+      if (!to->valid && nframes == 1 && ctx->adaptive_order == 1 && ctx->deep_class < 0 && ctx->grid_div == 0 && p.nchunks <= 32768) {
+        dp.sparse = true;
+        p.cold = ctx->cold_first && p.nchunks >= 2048 && p.nchunks <= 10000 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
+                 ps->tl_depth == rtk::kTreeletDepth;
       }
       p.deep_class = dp.deep_class;
       p.deep_split = dp.deep_split;
@@ -519,17 +494,6 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       }
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
-    if (p.cold_word && std::getenv("RT_COLD_DEBUG")) {   // (diagnostic: the hot list's word after the frame)
-      unsigned long long wd = 0;
-      unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipMemcpy(&wd, p.cold_word, 8, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(dbg, reinterpret_cast<char *>(p.cold_word) + 64, sizeof dbg, hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "  counters (RT_COLD_COUNTERS builds): looks %u, took an entry %u, holding a reservation %u, saw the end %u; dry passes %u, cap exits %u, end exits %u\n",
-                   dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
-      std::fprintf(stderr, "cold frame %dx%d: nscout %d, limit %d tiles; word: appended %llu, taken %llu, scout tiles finished %llu\n", p.w, p.h,
-                   p.cold_nscout, p.cold_limit, wd & 0xffffffull, (wd >> 24) & 0xffffffull, wd >> 48);
-    }
     if (to && p.cost) {
       // next frames' ticket -> tile table from this frame's record (also clears the record)
       if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
@@ -618,7 +582,6 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
-  if (ctx->cold_buf) (void)hipFree(ctx->cold_buf);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   if (ctx->arena) (void)hipFree(ctx->arena);
@@ -702,10 +665,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->adaptive_order = v;
   } else if (k == "box2") {
     ctx->box2 = v != 0;
-  } else if (k == "scout") {
-    ctx->scout = v != 0;
-  } else if (k == "cold_hold_depth") {
-    ctx->cold_hold_depth = std::max(1, std::min(64, v));
+  } else if (k == "cold_first") {
+    ctx->cold_first = v != 0;
   } else if (k == "solo") {
     ctx->solo = v != 0;
   } else if (k == "treelet") {

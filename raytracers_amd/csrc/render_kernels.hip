@@ -521,26 +521,12 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
-// COLD: the instantiation for the FIRST frame of a view -- no tile order exists yet, and in raster order the frame's longest
-// bounce chains start wherever the queue reaches their tiles (irreg 1000x1000: ~0.25 ms into the frame, + 0.34 ms of chain).
-// Which tiles hold long chains shows early, though: long chains CLUSTER, and a pixel whose chain is still alive after three
-// bounces marks its neighbourhood (irreg: the 7 % of the tiles around such pixels, taken at every fourth row and column,
-// hold every chain of >= 32 bounces and 99 % of those of >= 16; tools/cold_probe.py's notes).  So:
-//   * the first queue positions are SCOUT tiles: 8 x 8 pixels of the frame at every cold_div-th row and column, traced with a
-//     bounce limit of cold_bounces by the first waves of the launch (static tickets) while the others start on the tiles in
-//     raster order.  A scout ray's result is never stored; a scout ray that reaches the limit alive (black: ray_colour returns
-//     light * 0 when the budget is spent, ray.fut:136-147) CLAIMS the tile around its pixel and appends it, in quarters, to a
-//     HOT LIST in device memory;
-//   * every tile has one owner: the raster ticket that reaches it first or the hot list (atomicExch on cold_claim[tile]);
-//   * a wave that needs a ticket looks at the hot list first (one 64-bit read-modify-write that changes nothing -- the only
-//     reliable read of another XCD's counter --, one compare-and-swap to take an entry) and serves a hot quarter like a deep
-//     tile: no refill until it is finished;
-//   * a wave that finds itself carrying a ray of depth >= cold_hold_depth stops refilling too (a long chain no scout saw),
-//     and a wave that cannot refill and is left with ONE live ray at a bounce boundary hands it to solo_trace from inside
-//     the loop -- that call costs this instantiation 4-7 %, which a frame that would otherwise wait ~7 us
-//     per bounce for its longest chain gets back many times over.
-// Nothing of this touches a pixel's arithmetic: the frame is the ordinary kernel's, bit for bit.  Single whole frames only
-// (no partition, no batch), one tile per ticket, no order table.
+// COLD: the instantiation for the FIRST frame of a view at small sizes (no tile order yet: the frame's longest bounce chains
+// start wherever the raster order finds them, and a small frame's time is what they take from there).  A wave that cannot
+// refill any more (the queue is dry) and is left with ONE live ray at a bounce boundary hands it to solo_trace from INSIDE
+// the loop.  The call costs this instantiation 4-7 % in every regime: worth it on first frames of up to
+// ~800 x 800 pixels (rgbbox 500 x 500: 0.395 -> 0.333 ms, 700 x 700: 0.503 -> 0.474), not on larger ones
+// (profiles/r04/exp/e7_first_frames_full_grid_vs_cold.txt).
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool COLD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
@@ -610,30 +596,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
     qc.home_waves = nwaves >> ns_log2;                       // the same for every shard (the grid is a multiple of nshards)
     qc.q_static = p.static_first ? qc.home_waves : 0u;
-    qc.extra_pos = COLD ? (unsigned)p.cold_nscout : 0u;
     return qc;
   };
   unsigned q_state = queue_state_init((int)(blockIdx.x & ((1u << ns_log2) - 1u)), p.static_first != 0);
   bool q_enter = false;    // a ticket was drawn: (re)derive the tile's position
-  // COLD: scout slots, the hot list (see the header)
-  bool scout = false;      // (per lane) the slot holds a scout ray: `pix` is the tile around its pixel, nothing is stored for it
-  bool hot_over = !COLD;   // every scout tile is finished and the hot list is empty: no further looks at it
-  bool q_hot = false;      // the ticket in hand came from the hot list
-  bool q_scout = false;    // the ticket in hand is a scout tile
-  int scout_owed = 0;      // scout tiles this wave has entered and not yet counted as finished
-  int my_res = -1;         // hot-list index this wave has reserved (its fetch-and-add came before the entry): it alone may take it
-  int dry_polls = 0;       // looks a staying wave has taken at the hot list since the tile queue ran dry (bounded: a safety net)
-  bool q_dry = false;      // the tile queue has run dry (a cold launch may still get hot entries then)
-  // The hot list's word as the OTHER XCDs' atomics left it: a compare-and-swap against a value the word never holds.  (It must
-  // be a read-modify-write the compiler cannot see through: `atomicAdd(p, 0)` is folded into an atomic LOAD, and a device-scope
-  // load may be served from this XCD's L2, which is not coherent with the others' -- measured here: waves polled a stale "scout
-  // tiles finished" count until their safety cap, 0.1-0.5 s per frame.)
-  auto cold_peek = [&]() { return atomicCAS(p.cold_word, ~0ull, ~0ull); };
-  auto cold_read = [&]() {
-    unsigned long long v = 0ull;
-    if (lane == 0) v = cold_peek();
-    return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v);
-  };
   // instrumented build only: per-wave timeline (rt_render_trace)
   unsigned long long tr_t0 = 0, tr_exh = 0, tr_c0 = 0, tr_ops[3] = {0, 0, 0}, tr_items[2] = {0, 0};
   unsigned long long tr_cyc[5] = {0, 0, 0, 0, 0}, tr_nt = 0, tr_nb2 = 0;   // shader cycles inside BOX / BOX2 / BOXT / LEAF / SHADE operations, treelet operations
@@ -749,33 +715,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             float t = best;
             if (hit && !rehit_is_best(best, ((unsigned)key & 1u) != 0u)) have = rehit_full(r, best, s.x, s.y, s.z, s.w, &t);
             int32_t pixel;
-            if (shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, (COLD && scout) ? p.cold_bounces : p.max_depth,
-                                 &pixel)) {
+            if (shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, p.max_depth, &pixel)) {
               root = true;
-            } else if (COLD && scout) {
-              // a scout ray: nothing is stored.  Black = still alive at the bounce limit (or absorbed): the tile around the pixel
-              // goes to the hot list, in quarters -- if nobody owns it yet and the list has room
-              // (the look at the list's length is an ordinary load -- possibly stale, it only keeps a scene whose scouts flag
-              // most tiles from flooding the list; the claim decides)
-              if (pixel == 0 && (unsigned)(__hip_atomic_load(p.cold_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffull) < 4u * (unsigned)p.cold_limit &&
-                  atomicExch(&p.cold_claim[pix], 1) == 0) {
-                const unsigned at = (unsigned)(atomicAdd(p.cold_word, 4ull) & 0xffffffull);
-                for (int k = 0; k < 4; ++k) atomicExch(&p.cold_hot[at + k], ((pix << 2) | k) + 1);
-              }
-              pix = -1;
-              scout = false;
             } else {
               p.out[pix] = pixel;
               pix = -1;
               // cost record for the adaptive tile order: the longest bounce chain seen in the tile
               if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
-            }
-          }
-          if constexpr (COLD) {
-            // this wave's scout tiles are finished (they are first tickets as a rule: handed out in one go): count them
-            if (scout_owed > 0 && !(q_scout && q_next != q_end) && bal(scout && pix >= 0) == 0ull) {
-              if (lane == 0) atomicAdd(p.cold_word, (unsigned long long)scout_owed << 48);
-              scout_owed = 0;
             }
           }
           bool want = (pix < 0) & !exhausted & !hold;
@@ -784,75 +730,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           while (m != 0ull) {            // wave-uniform loop
             if (__builtin_expect(q_next == q_end, 0)) {   // (cold: the register allocator must not favour the draw's values over the hot loop's)
               if (hold) break;           // a deep tile is in flight: no further tickets for now
-              if constexpr (COLD) {
-                // The hot list first.  One look (cold_read); an entry is taken with ONE fetch-and-add on the "taken" field -- no
-                // compare-and-swap loop: thousands of waves find the first entries at the same moment, and retries made that
-                // moment quadratic (measured: 50 ms for irreg's 2 000 entries, 300 ms for rgbbox's 10 000).  A wave whose add
-                // comes too late has RESERVED the index it got (my_res): the entry appended there later, if any, is its to take.
-                q_hot = false;
-                if (!hot_over) {
-                  const unsigned long long w = cold_read();
-                  const int tail = (int)(w & 0xffffffull), head = (int)((w >> 24) & 0xffffffull);
-                  const bool scouts_done = (int)(w >> 48) >= p.cold_nscout;   // (then `tail` is final)
-                  int take = -1;
-                  if (my_res >= 0) {
-                    if (tail > my_res) { take = my_res; my_res = -1; }
-                    else if (scouts_done) my_res = -1;     // nothing will ever be appended there
-                  } else if (head < tail) {
-                    unsigned long long w2 = 0ull;
-                    if (lane == 0) w2 = atomicAdd(p.cold_word, 1ull << 24);
-                    w2 = ((unsigned long long)(unsigned)uni((int)(w2 >> 32)) << 32) | (unsigned)uni((int)w2);
-                    const int h = (int)((w2 >> 24) & 0xffffffull);
-                    if (h < (int)(w2 & 0xffffffull)) take = h;
-                    else my_res = h;
-                  }
-                  if (take >= 0) {
-                    int e = 0, spins = 0;             // the entry's value may still be on its way (the producer publishes the index first)
-                    do {
-                      if (lane == 0) e = atomicCAS(&p.cold_hot[take], -1, -1);   // (the same kind of read: see cold_peek)
-                      e = uni(e);
-                    } while (e == 0 && ++spins < (1 << 20));
-                    if (e != 0) {                     // (e == 0 cannot happen: the producer writes the value right behind the index)
-                      e -= 1;
-                      q_next = ((unsigned)(p.cold_nscout + (e >> 2)) << 6) + 16u * (unsigned)(e & 3);
-                      q_end = q_next + 16u;
-                      q_enter = true;
-                      q_hot = true;
-                    }
-                  } else if (my_res < 0 && scouts_done && head >= tail) {
-                    hot_over = true;
-                  }
-#ifdef RT_COLD_COUNTERS
-                  if (lane == 0) {
-                    unsigned *dbg = reinterpret_cast<unsigned *>(p.cold_word) + 16;
-                    atomicAdd(&dbg[0], 1u);
-                    if (take >= 0) atomicAdd(&dbg[1], 1u);
-                    if (my_res >= 0) atomicAdd(&dbg[2], 1u);
-                    if (hot_over) atomicAdd(&dbg[3], 1u);
-                  }
-#endif
-                }
-                if (q_hot) continue;                  // (to the tile-entry code below, through the loop's head: q_next != q_end now)
-                if (q_dry) {
-                  // No tiles left.  Once the queue is dry every tile has an owner, so a scout can append nothing any more -- except a
-                  // tile whose raster ticket is drawn but has not reached its claim yet.  For those (and for entries nobody has taken
-                  // yet) a FEW waves stay and look again, with a pause: wave 0 of every eighth workgroup.  Everybody else leaves: 4096
-                  // waves polling one word starve the very atomics they wait for (measured: 0.2-0.6 s per frame).
-                  if (!hot_over && my_res < 0 && (wave != 0 || (blockIdx.x & 7u) != 0u)) hot_over = true;
-                  if (!hot_over) __builtin_amdgcn_s_sleep(64);
-                  dry_polls = uni(dry_polls + 1);
-#ifdef RT_COLD_COUNTERS
-                  if (lane == 0) {
-                    unsigned *dbg = reinterpret_cast<unsigned *>(p.cold_word) + 16;
-                    atomicAdd(&dbg[4], 1u);
-                    if (!hot_over && dry_polls > p.cold_poll_cap) atomicAdd(&dbg[5], 1u);
-                    if (hot_over) atomicAdd(&dbg[6], 1u);
-                  }
-#endif
-                  if (hot_over || dry_polls > p.cold_poll_cap) exhausted = true;
-                  break;
-                }
-              }
               // A ticket: 1 << tpt_log2 consecutive positions of a shard's segment (a batch launch and a large frame draw
               // four tiles at a time: 4096 waves on one counter otherwise saturate it -- ~90 atomics per microsecond --
               // before they saturate the chip), except that the first tickets of a shard are pieces of its deepest tiles
@@ -866,12 +743,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 return (unsigned)__builtin_amdgcn_readfirstlane(v);
               }, &sp);
               if (!got) {
-                if (COLD) {
-                  q_dry = true;
-                  if (hot_over) exhausted = true;
-                } else {
-                  exhausted = true;
-                }
+                exhausted = true;
                 if (STATS) tr_exh = wall_clock64();
                 break;
               }
@@ -881,34 +753,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             }
             if (__builtin_expect(q_enter || (q_next & 63u) == 0u, 0)) {
               q_enter = false;
-              if constexpr (COLD) {
-                // position -> scout tile, or tile (raster order; no order table, one frame)
-                const int t = (int)(q_next >> 6);
-                q_scout = t < p.cold_nscout;
-                if (q_scout) {
-                  scout_owed = uni(scout_owed + 1);
-                  q_tile = t;
-                  const int sty = t / p.cold_stx;
-                  q_col0 = (t - sty * p.cold_stx) * 8;
-                  q_row0 = sty * 8;
-                } else {
-                  q_tile = t - p.cold_nscout;
-                  if (!q_hot) {   // a raster ticket owns its tile only if no scout got there first
-                    int old = 0;
-                    if (lane == 0) old = atomicExch(&p.cold_claim[q_tile], 1);
-                    if (uni(old) != 0) {
-                      q_next = q_end;
-                      continue;
-                    }
-                  } else {
-                    hold = true;
-                    __builtin_amdgcn_s_setprio(3);
-                  }
-                  const int ty = q_tile / p.tiles_x;
-                  q_col0 = (q_tile - ty * p.tiles_x) * 8;
-                  q_row0 = ty * 8;
-                }
-              } else {
               // entering a tile: where it is.  A batch launch hands out the tiles of frame 0, then of frame 1, ...:
               // frame f's pixels go to out + f * frame_stride and (when the batch carries cameras) through cams[f]
               unsigned t = q_next >> 6;
@@ -948,24 +792,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               const int ty = q_tile / p.tiles_x;                    // once per tile, scalar
               q_col0 = (q_tile - ty * p.tiles_x) * 8;
               q_row0 = ty * 8;
-              }
             }
             const unsigned rest = 64u - (q_next & 63u), avail = rest < q_end - q_next ? rest : q_end - q_next;   // rest of the current tile / piece
             const unsigned rank = (unsigned)lane_rank(m);
             const unsigned cnt = (unsigned)__popcll(m);
-            if (COLD && q_scout) {
-              if (want & (rank < avail)) {
-                const int within = (int)((q_next + rank) & 63u);
-                const int sc = q_col0 + (within & 7), sr = q_row0 + (within >> 3);
-                if (sc < p.cold_ws && sr < p.cold_hs) {   // the scout grid's pixel -> a pixel of the frame (whole frames: local row = row)
-                  const int fcol = min(p.cold_div * sc + 1, p.w - 1), frow = min(p.cold_div * sr + 1, p.h - 1);
-                  slot = (frow >> 3) * p.tiles_x + (fcol >> 3);   // (what a scout slot keeps in `pix`: the tile around its pixel)
-                  scout = true;
-                  primary_dir_uv(q_cam, p.u_tab[fcol], p.v_tab[frow], r);
-                  want = false;
-                }
-              }
-            } else if (want & (rank < avail)) {
+            if (want & (rank < avail)) {
               const int within = (int)((q_next + rank) & 63u);
               const int col = q_col0 + (within & 7), lrow = q_row0 + (within >> 3);
               if (col < p.w && lrow < p.rows_local) {
@@ -988,15 +819,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             root = true;
           }
           if constexpr (COLD) {
+            // (the lists are empty here -- SHADE runs behind the drained leaf list, and nbox == 0 is asked for -- so the wave's LDS
+            // region is free for the solo loop)
             const unsigned long long m_l = bal(pix >= 0);
-            if (!hold && bal(pix >= 0 && depth >= p.cold_hold_depth) != 0ull) {   // a long chain no scout saw: this wave serves it from now on
-              hold = true;
-              __builtin_amdgcn_s_setprio(3);
-            }
-            // (the lists are empty here -- SHADE runs behind the drained leaf list with nbox == 0 for a holding wave -- so the
-            // wave's LDS region is free for the solo loop)
-            if ((hold || exhausted) && nbox == 0 && m_l != 0ull && (m_l & (m_l - 1ull)) == 0ull && bal(root && !scout) == m_l &&
-                p.tl_log2 == kTreeletDepth) {
+            if ((hold || exhausted) && nbox == 0 && m_l != 0ull && (m_l & (m_l - 1ull)) == 0ull && bal(root) == m_l && p.tl_log2 == kTreeletDepth) {
               const int src = uni((int)__builtin_ctzll(m_l));
               auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
               solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
@@ -1515,8 +1341,8 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
-  // (COLD: the first frame of a view; workgroups of 16 waves only -- the host asks for it on no other shape)
-  if (p.cold_word != nullptr && waves_per_wg == 16 && !solo)
+  // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
+  if (p.cold && waves_per_wg == 16 && !solo)
     return all_lds ? launch_pooled_t<1024, true, false, false, true>(p, grid, stream)
                    : launch_pooled_t<1024, false, false, false, true>(p, grid, stream);
 #define RT_POOLED_CASE(W)                                                                                               \

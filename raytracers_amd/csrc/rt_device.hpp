@@ -92,7 +92,6 @@ struct QueueConst {
   int deep_class;            // 0: no deep tiles
   unsigned home_waves;       // waves whose home is one shard (total waves >> ns_log2)
   unsigned q_static;         // tickets [0, q_static) of every shard are the home waves' first tickets: never drawn from the counter
-  unsigned extra_pos;        // positions AHEAD of the tiles' (a cold frame's scout tiles, render_kernels.hip): position k of the queue is tile k - extra_pos
 };
 // A wave's queue state is one word (it lives in an SGPR across the whole render loop):
 // bits 0-2 the shard being drawn from, bit 7 "the first draw is still to come", bits 8-15 the shards seen dry.
@@ -121,7 +120,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
     const int sh = queue_shard(state);
     const int geo = c.interleave ? 0 : sh;
     const Shard s = shard_of(geo, queue_geo_log2(c), c.tiles_x, c.tiles_y);
-    const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes + c.extra_pos;
+    const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
     const int ndeep = queue_ndeep(c, geo);               // (<= the shard's tiles: a position of its class table)
     const unsigned n_split = queue_nsplit(c, ndeep);
     unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
@@ -193,17 +192,7 @@ struct KParams {
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
-  // pooled family, COLD instantiation (the first frame of a view; see the kernel's header).  cold_word == nullptr: not a cold launch
-  unsigned long long *cold_word;   // {entries appended to the hot list: bits 0-23, entries taken: 24-47, scout tiles finished: 48-63}; zero at launch
-  int *cold_claim;       // [nchunks] 1: the tile has an owner (the raster ticket that reached it first, or the hot list); zero at launch
-  int *cold_hot;         // [4 * nchunks] hot list: ((tile << 2) | quarter) + 1; zero (= not written yet) at launch
-  int cold_nscout;       // scout tiles: 8 x 8 pixels of the frame taken every cold_div-th row and column; they are queue positions [0, cold_nscout)
-  int cold_stx;          // scout tiles per row
-  int cold_hs, cold_ws;  // the scout grid: ceil(h / cold_div) x ceil(w / cold_div)
-  int cold_div, cold_bounces;      // 4, 3
-  int cold_limit;        // at most this many tiles go through the hot list (a quarter of the launch's waves: one piece per wave)
-  int cold_hold_depth;   // a wave carrying a ray of this depth stops refilling
-  int cold_poll_cap;     // looks a wave with nothing left to draw takes at the hot list before it leaves regardless (a safety net)
+  int cold;              // pooled family: the COLD instantiation (a view's first frame at a small size): in-loop hand-over of a wave's last ray to the solo loop
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)

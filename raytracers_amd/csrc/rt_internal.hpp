@@ -33,10 +33,7 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
-  int scout = 1;            // pooled family: the FIRST frame of a view is rendered by the COLD instantiation (scout tiles + hot list, render_kernels.hip; 0: the ordinary kernel in raster order)
-  int cold_hold_depth = 12; // ... in which a wave carrying a ray of this depth stops refilling
-  char *cold_buf = nullptr; // its device block: the hot list's word, the tiles' owners, the hot list (grown on demand, zeroed per cold launch)
-  size_t cold_bytes = 0;
+  int cold_first = 1;       // pooled family: a view's FIRST frame (no tile order yet) of at most ~800 x 800 pixels is rendered by the COLD instantiation (render_kernels.hip; 0: the ordinary kernel)
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
   int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)

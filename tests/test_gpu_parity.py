@@ -227,24 +227,20 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
     c.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(scout=0), dict(cold_hold_depth=1), dict(cold_hold_depth=3, thr_shade=8), dict(cold_hold_depth=50),
-                                  dict(gpu_build=0), dict(box2=0, cold_hold_depth=2), dict(static_first=0), dict(xcd_queues=0),
-                                  dict(xcd_queues=0, static_first=0, thr_shade=64), dict(xcd_queues=1)])
-def test_scouted_first_frames(R, opts):
-    """A view's FIRST frame through the COLD instantiation: scout tiles at the head of the queue, the hot list of the tiles
-    they flag (every tile rendered exactly once: by the raster ticket that reached it first or through the hot list, in
-    quarters), dynamic hold, hand-over of a wave's last ray to the solo loop from inside the loop -- and the pixels of the
-    frame are the oracle's, on the scene where the scouts discriminate (irreg), on the one where they flag most tiles
-    (rgbbox: the hot list fills up to its limit), on a random scene, at sizes on either side of the range; every frame is a
-    new view (fresh prepared scenes and a camera path), into a poisoned buffer; scout tiles as static first tickets and drawn
-    from the counters, one ticket counter and eight."""
+@pytest.mark.parametrize("opts", [dict(), dict(cold_first=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
+                                  dict(xcd_queues=0, thr_shade=64)])
+def test_first_frames_of_new_views(R, opts):
+    """A view's FIRST frame (no tile order yet) runs on every workgroup and, at small sizes, through the COLD instantiation (a
+    wave that cannot refill hands its last ray to the solo loop from INSIDE the pooled loop): the pixels of the frame are
+    the oracle's, on both scenes and a random one, at sizes on either side of the range the instantiation is used for;
+    every frame is a new view (fresh prepared scenes and a camera path), into a poisoned buffer."""
     import bench
     import torch
     c = R.Context()
     for k, v in opts.items():
         c.set_option(k, v)
     cks = bench.Checksummer(torch.device("cuda"))
-    for scene, h, w in (("irreg", 1000, 1000), ("rgbbox", 1000, 1000), ("irreg", 500, 500), ("rgbbox", 360, 360), ("irreg", 1400, 1400)):
+    for scene, h, w in (("irreg", 1000, 1000), ("rgbbox", 700, 700), ("irreg", 500, 500), ("rgbbox", 360, 360), ("rgbbox", 500, 500)):
         ps = R.prepare_scene(h, w, c.scene(scene))
         img = torch.full((h, w), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
@@ -270,13 +266,13 @@ def test_scouted_first_frames(R, opts):
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 one = img.clone()
-                c.set_option("scout", 0)
+                c.set_option("cold_first", 0)
                 c.set_option("adaptive_order", 0)
                 img.fill_(0x5a5a5a5a)
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 c.set_option("adaptive_order", 1)
-                c.set_option("scout", opts.get("scout", 1))
+                c.set_option("cold_first", opts.get("cold_first", 1))
                 assert bool((img == one).all()), (scene, f)
         ps.free()
     rng = np.random.default_rng(11)

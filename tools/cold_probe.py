@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First frames of views never seen before (the stateless figure: the reference's render keeps nothing between calls).
 For each scene and option set: a fresh prepared scene per repetition, the first frame's time (events around the call,
-scout + order + frame + the exact order's sort), the image's checksum against the oracle's table; then a 12-view camera
+the frame + the tile order's sort), the image's checksum against the oracle's table; then a 12-view camera
 path rendered view by view.   usage: cold_probe.py [size=1000] ["opt=v,opt=v" ...]"""
 import os
 import sys
@@ -14,7 +14,7 @@ import bench
 import raytracers_amd as R
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-sets = sys.argv[2:] or ["scout=0", "scout=1"]
+sets = sys.argv[2:] or ["cold_first=0", "cold_first=1"]
 dev = torch.device("cuda", 0)
 cks = bench.Checksummer(dev)
 for spec in sets:

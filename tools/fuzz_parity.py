@@ -65,8 +65,8 @@ while time.time() < t_end:
                  static_first=int(rng.choice([0, 1, 1])),
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
                  treelet=int(rng.choice([2, 2, 2, 1, 4])),
-                 # a view's first frame: scout frame + COLD instantiation (dynamic hold depth)
-                 scout=int(rng.choice([0, 1, 1])), cold_hold_depth=int(rng.choice([1, 2, 4, 12, 12, 50])))
+                 # a view's first frame at a small size: the COLD instantiation (in-loop hand-over to the solo loop)
+                 cold_first=int(rng.choice([0, 1, 1])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):

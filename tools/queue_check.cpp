@@ -57,7 +57,6 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
   qc.order = deep_on ? order.data() : nullptr; qc.deep_class = c.deep_class;
   qc.home_waves = static_cast<unsigned>(c.waves >> c.ns_log2);
   qc.q_static = c.static_first ? qc.home_waves : 0u;
-  qc.extra_pos = 0u;
 
   std::vector<unsigned> counter(static_cast<size_t>(ns), 0u), draws(static_cast<size_t>(ns), 0u);
   std::vector<unsigned char> cover(static_cast<size_t>(ntiles) * c.nframes * 64, 0);
