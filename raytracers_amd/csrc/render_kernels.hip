@@ -1365,6 +1365,11 @@ void warm_render_kernels() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false>);
+  // (the instantiations a view's first frames and its policy may switch to: a first use inside somebody's timed loop is 0.2-0.3 ms)
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, true>);
   (void)hipFuncGetAttributes(&a, (const void *)tile_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_place_kernel);

@@ -44,9 +44,9 @@ big = HipPartRenderer("irreg", 4000, 4000, dev)
 
 
 def timed(fn, reps=5, warm=3, sync_each=False):
-    for _ in range(warm):
+    for _ in range(warm + 1):        # (render + sync: a view's deep-tile policy reaches the host asynchronously)
         fn()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
