@@ -474,13 +474,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
       // A view's FIRST frame (no order yet): every workgroup -- the half-size launch that serves a partly LDS-resident scene's
       // ordered frames best lets an unordered one wait for its late chains with half the chip (irreg, first frame: 700 x 700
-      // 0.605 -> 0.545 ms, 1000 x 1000 0.714 -> 0.625, 1400 x 1400 0.909 -> 0.738) -- and, up to ~800 x 800 pixels, the
-      // COLD instantiation (profiles/r04/exp/e7_first_frames_full_grid_vs_cold.txt).
+      // 0.605 -> 0.545 ms, 1000 x 1000 0.714 -> 0.625, 1400 x 1400 0.909 -> 0.738; profiles/r04/exp/e7).
       if (!to->valid && nframes == 1 && ctx->adaptive_order == 1 && ctx->deep_class < 0 && ctx->grid_div == 0 && p.nchunks <= 32768) {
         dp.sparse = true;
-        p.cold = ctx->cold_first && p.nchunks >= 2048 && p.nchunks <= 10000 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
-                 ps->tl_depth == rtk::kTreeletDepth;
       }
+      // Small single frames (2 048 .. 10 000 tiles), ordered or not, are what their last bounce chains take: the COLD instantiation
+      // hands a wave's last ray (a first frame) or last three (an ordered one) to the solo loop from inside the pooled loop --
+      // rgbbox 500 x 500: first frame 0.395 -> 0.333 ms, later frames 0.280 -> 0.225; neutral to +2 % from 1000 x 1000 on, where it
+      // is not used (profiles/r04/exp/e7, e8).
+      if (ctx->handover && nframes == 1 && p.nchunks >= 2048 && p.nchunks <= 10000 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
+          ps->tl_depth == rtk::kTreeletDepth && ctx->deep_class < 0 && ctx->adaptive_order == 1)
+        p.cold = to->valid ? 3 : 1;
       p.deep_class = dp.deep_class;
       p.deep_split = dp.deep_split;
       p.deep_cap_log2 = dp.cap_log2;
@@ -665,8 +669,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->adaptive_order = v;
   } else if (k == "box2") {
     ctx->box2 = v != 0;
-  } else if (k == "cold_first") {
-    ctx->cold_first = v != 0;
+  } else if (k == "handover") {
+    ctx->handover = v != 0;
   } else if (k == "solo") {
     ctx->solo = v != 0;
   } else if (k == "treelet") {

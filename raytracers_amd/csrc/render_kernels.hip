@@ -521,12 +521,12 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 //
 // ALL_LDS: the whole traversal copy (nodes + sphere table) is staged in LDS, so the global
 // (buffer_load) path is compiled out.
-// COLD: the instantiation for the FIRST frame of a view at small sizes (no tile order yet: the frame's longest bounce chains
-// start wherever the raster order finds them, and a small frame's time is what they take from there).  A wave that cannot
-// refill any more (the queue is dry) and is left with ONE live ray at a bounce boundary hands it to solo_trace from INSIDE
-// the loop.  The call costs this instantiation 4-7 % in every regime: worth it on first frames of up to
-// ~800 x 800 pixels (rgbbox 500 x 500: 0.395 -> 0.333 ms, 700 x 700: 0.503 -> 0.474), not on larger ones
-// (profiles/r04/exp/e7_first_frames_full_grid_vs_cold.txt).
+// COLD: the instantiation for SMALL single frames (~360 x 360 .. 800 x 800 pixels), whose time is what their last bounce chains
+// take.  A wave that cannot refill any more (the queue is dry, or it holds a deep tile) and is left with at most p.cold live
+// rays, all at a bounce boundary, hands them to solo_trace one after the other from INSIDE the loop.  The call costs this
+// instantiation 4-7 % in every regime -- which is why the kernels of larger frames and batches do not have
+// it -- and a small frame gets it back: rgbbox 500 x 500, first frame 0.395 -> 0.333 ms (one ray), later frames 0.280 -> 0.225
+// (three); at 1000 x 1000 it is neutral to +2 % (profiles/r04/exp/e7, e8).
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool COLD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   extern __shared__ float4 smem[];
@@ -819,17 +819,20 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             root = true;
           }
           if constexpr (COLD) {
-            // (the lists are empty here -- SHADE runs behind the drained leaf list, and nbox == 0 is asked for -- so the wave's LDS
-            // region is free for the solo loop)
-            const unsigned long long m_l = bal(pix >= 0);
-            if ((hold || exhausted) && nbox == 0 && m_l != 0ull && (m_l & (m_l - 1ull)) == 0ull && bal(root) == m_l && p.tl_log2 == kTreeletDepth) {
-              const int src = uni((int)__builtin_ctzll(m_l));
-              auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-              solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
-                         rl(r.oz), rl(r.dx), rl(r.dy), rl(r.dz), rl(lr), rl(lg), rl(lb), __builtin_amdgcn_readlane(pix, src),
-                         __builtin_amdgcn_readlane(depth, src), __builtin_amdgcn_readlane(ptile, src));
+            // (the lists are empty here -- SHADE runs behind the drained leaf list, and nbox == 0 is asked for: every live ray then
+            // stands at a bounce boundary -- so the wave's LDS region is free for the solo loop)
+            unsigned long long m_l = bal(pix >= 0);
+            if ((hold || exhausted) && nbox == 0 && m_l != 0ull && (int)__popcll(m_l) <= p.cold && bal(root) == m_l && p.tl_log2 == kTreeletDepth) {
+              while (m_l != 0ull) {          // the last few rays, one after the other
+                const int src = uni((int)__builtin_ctzll(m_l));
+                m_l &= m_l - 1ull;
+                auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+                solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
+                           rl(r.oz), rl(r.dx), rl(r.dy), rl(r.dz), rl(lr), rl(lg), rl(lb), __builtin_amdgcn_readlane(pix, src),
+                           __builtin_amdgcn_readlane(depth, src), __builtin_amdgcn_readlane(ptile, src));
+              }
               wkey[lane] = kKeyInit;     // (the solo loop used key 0 and the lists)
-              pix = -1;                  // the one live slot is done: its pixel is stored
+              pix = -1;                  // the live slots are done: their pixels are stored
               root = false;
             }
           }
@@ -1342,9 +1345,9 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
   // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
-  if (p.cold && waves_per_wg == 16 && !solo)
-    return all_lds ? launch_pooled_t<1024, true, false, false, true>(p, grid, stream)
-                   : launch_pooled_t<1024, false, false, false, true>(p, grid, stream);
+  if (p.cold && waves_per_wg == 16)
+    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, true>(p, grid, stream) : launch_pooled_t<1024, true, false, false, true>(p, grid, stream))
+                   : (solo ? launch_pooled_t<1024, false, false, true, true>(p, grid, stream) : launch_pooled_t<1024, false, false, false, true>(p, grid, stream));
 #define RT_POOLED_CASE(W)                                                                                               \
   case W:                                                                                                               \
     return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \

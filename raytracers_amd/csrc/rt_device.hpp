@@ -192,7 +192,7 @@ struct KParams {
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
-  int cold;              // pooled family: the COLD instantiation (a view's first frame at a small size): in-loop hand-over of a wave's last ray to the solo loop
+  int cold;              // pooled family: > 0 = the COLD instantiation: a wave that cannot refill hands its last `cold` rays to the solo loop from inside the pooled loop
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)

@@ -227,7 +227,7 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
     c.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(cold_first=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
+@pytest.mark.parametrize("opts", [dict(), dict(handover=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
                                   dict(xcd_queues=0, thr_shade=64)])
 def test_first_frames_of_new_views(R, opts):
     """A view's FIRST frame (no tile order yet) runs on every workgroup and, at small sizes, through the COLD instantiation (a
@@ -266,13 +266,13 @@ def test_first_frames_of_new_views(R, opts):
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 one = img.clone()
-                c.set_option("cold_first", 0)
+                c.set_option("handover", 0)
                 c.set_option("adaptive_order", 0)
                 img.fill_(0x5a5a5a5a)
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 c.set_option("adaptive_order", 1)
-                c.set_option("cold_first", opts.get("cold_first", 1))
+                c.set_option("handover", opts.get("handover", 1))
                 assert bool((img == one).all()), (scene, f)
         ps.free()
     rng = np.random.default_rng(11)

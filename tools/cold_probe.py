@@ -14,7 +14,7 @@ import bench
 import raytracers_amd as R
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-sets = sys.argv[2:] or ["cold_first=0", "cold_first=1"]
+sets = sys.argv[2:] or ["handover=0", "handover=1"]
 dev = torch.device("cuda", 0)
 cks = bench.Checksummer(dev)
 for spec in sets:
