@@ -104,12 +104,39 @@ def bytes_alg(box, sph, h, w):
     return 32 * box + 16 * sph + 4 * h * w
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources: profiles/pmc.json records the hash it was measured on"""
+def strip_comments(src):
+    """C++ source without comments and with white space collapsed (string and character literals kept as they are): what the
+    compiler sees, so that an edited comment does not invalidate counters measured on unchanged code"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith("//", i):
+            while i < n and src[i] != "\n":
+                i += 1
+        elif src.startswith("/*", i):
+            i = src.find("*/", i + 2)
+            i = n if i < 0 else i + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+def kernel_source_hash(legacy=False):
+    """sha256 over the kernel sources (comments and white space removed): profiles/pmc.json records the hash it was measured on.
+    legacy=True: over the raw bytes (what files written before round 4's last commit carry)"""
     m = hashlib.sha256()
     for rel in KERNEL_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
-            m.update(f.read())
+            raw = f.read()
+        m.update(raw if legacy else strip_comments(raw.decode("utf-8")).encode("utf-8"))
     return m.hexdigest()
 
 

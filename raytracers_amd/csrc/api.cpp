@@ -1110,7 +1110,10 @@ extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h
 
 // Diagnostic: one instrumented pooled launch that records, per wave, clock64 at start / at
 // queue exhaustion / at exit, the number of BOX / LEAF / SHADE operations, the items they
-// processed ((box << 32) | leaf) and the deepest bounce chain finished.  records: waves x 8 u64.
+// processed ((box << 32) | leaf) and the deepest bounce chain finished.  records: waves x 16 u64.
+// The instrumented instantiation has neither the solo prologue nor the in-loop hand-over: for a view whose policy hands out
+// single-pixel tickets (irreg 1000x1000) those tickets go through the pooled loop here, so the timeline overstates that
+// view's longest chains by the difference between the two (~7 against ~4.5 us per bounce).
 extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                                uint64_t *records, int32_t max_waves, int32_t *num_waves) {
   if (!ctx || !ps || !records || !num_waves) return fail(ctx, "null argument");

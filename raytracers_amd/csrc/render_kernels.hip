@@ -376,8 +376,10 @@ __device__ __forceinline__ float pull(int lane_byte, float v) {   // v of the la
 // A frame cannot end before its longest bounce chain does (irreg 1000x1000: 10 pixels of 45-49 scatters, each scatter a
 // fold that depends on the one before), and in the pooled loop a wave that serves ONE ray still pays every operation's
 // general machinery: ~5 traversal operations + LEAF + SHADE per bounce at 1700-3900 shader cycles each = ~7 us per bounce
-// (profiles/r03/exp/e10_trace.txt).  When a wave that cannot refill (queue dry, or a held deep tile) is left with a single
-// live ray, it finishes that pixel here instead: the ray lives in registers (the same value in every lane), the fold is
+// (profiles/r03/exp/e10_trace.txt).  solo_trace finishes ONE pixel with the whole wave behind it -- called from the SOLO
+// instantiation's prologue for single-pixel tickets (the deepest tiles of an ordered view, all of them first tickets) and, in
+// the COLD instantiation, from inside the loop for the last rays of a wave that cannot refill.  The ray lives in registers (the
+// same value in every lane), the fold is
 // a loop of TREELET operations -- 2^D lanes per popped treelet root, every lane tests the boxes of both children of one
 // node of the treelet speculatively, a node counts iff the boxes on its path inside the treelet passed (treelet.h: the
 // fixed (0, 1e9) box interval makes a box test independent of when it is made) -- and of sphere tests folded with one LDS

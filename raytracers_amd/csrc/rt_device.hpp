@@ -194,7 +194,7 @@ struct KParams {
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int cold;              // pooled family: > 0 = the COLD instantiation: a wave that cannot refill hands its last `cold` rays to the solo loop from inside the pooled loop
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
-  int solo;              // pooled family: a wave that cannot refill and is left with one ray finishes that pixel in solo_trace (0: off)
+  int solo;              // pooled family: single-pixel tickets (deep_split == 6) are traced by solo_trace in a PROLOGUE ahead of the pooled loop (the SOLO instantiation; 0: off).  The hand-over of a wave's last rays from INSIDE the loop is `cold`, below
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)
   int deep_class;        // a shard's positions below its class table's entry [deep_class] are "deep" tiles (0: feature off)
   int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)
