@@ -205,7 +205,8 @@ class ShardedStep:
         if self.exchange_mode != "direct":
             return
         self.images = None
-        torch.cuda.synchronize(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         if self.rank != self.dst:
             self._release_direct()
         if dist.is_initialized():
@@ -217,7 +218,8 @@ class ShardedStep:
         """one element all-reduced on the current stream: behind it every rank's earlier work on ITS stream has completed
         (gloo test mode: a host barrier behind a device sync)"""
         if self.cpu_backend:
-            torch.cuda.synchronize(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
         else:
             dist.all_reduce(self.flag, group=self.group)
