@@ -662,6 +662,7 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         n_verified += verify([big_lane], "irreg 4000x4000,")
         # ... and the same frames as ONE batch launch per rank (one frame at a time cannot end before its longest bounce chain)
+        big_lane.step.close()             # (direct exchange: the other ranks unmap rank 0's images before it frees them; collective)
         del big_lane
         bb = Lane(opts, fr4, nbatch=n4)
         for _ in range(2):
@@ -675,6 +676,7 @@ def main():
         tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         n_verified += verify([bb], "irreg 4000x4000 batch,")
+        bb.step.close()
         del bb
         if rank == 0:
             r4 = FRAME_WORK[("irreg", 4000, 4000)][0]
@@ -783,6 +785,8 @@ def main():
     else:
         result_line = None
     if use_pg:
+        for ln in lanes + ([serial_lane] if serial_lane is not None else []):
+            ln.step.close()               # (a no-op for the gather exchange)
         dist.barrier()
         dist.destroy_process_group()
     # RCCL's banner sits in the C library's stdout buffer (a pipe is fully buffered) and would
