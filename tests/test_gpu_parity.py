@@ -254,6 +254,7 @@ def test_first_frames_of_new_views(R, opts):
         first = img.clone()
         for _ in range(2):                     # the view's second and third frame (exact order, then the policy)
             img.fill_(0x5a5a5a5a)
+            torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
             R.render_into(img.data_ptr(), h, w, ps)
             c.sync()
             assert bool((img == first).all())
@@ -263,12 +264,14 @@ def test_first_frames_of_new_views(R, opts):
             for f in range(4):
                 cam = orc.camera_floats(h + 8 * f, w)
                 img.fill_(0x5a5a5a5a)
+                torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 one = img.clone()
                 c.set_option("handover", 0)
                 c.set_option("adaptive_order", 0)
                 img.fill_(0x5a5a5a5a)
+                torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
                 R.render_into(img.data_ptr(), h, w, ps, cam=cam)
                 c.sync()
                 c.set_option("adaptive_order", 1)
@@ -457,11 +460,14 @@ def test_camera_path_one_frame_at_a_time(R, scene, h, w):
     c.close(); plain.close()
 
 
-def test_random_parity_campaign():
-    """tools/fuzz_parity.py: a few seconds of random scenes / cameras / sizes / bounce limits, both
-    BVH builders and all kernel families against the oracle (a 200 s run covered 29 337 cases)."""
+@pytest.mark.parametrize("seconds,seed,side,spheres", [(15, 77000, 160, 20000), (15, 88000, 520, 60000)])
+def test_random_parity_campaign(seconds, seed, side, spheres):
+    """tools/fuzz_parity.py as a gate of the driver-run suite, half a minute of it: random scenes /
+    cameras / sizes / bounce limits / launch knobs / partitions (packed and in place), both BVH builders and all kernel
+    families against the oracle -- small images (~1 000 cases) and images large enough for the first-frame policy and the
+    in-loop hand-over (~150 cases).  (The rounds' long runs: profiles/rNN/fuzz_*_final.txt.)"""
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "8", "77000"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seconds), str(seed), str(side), str(spheres)],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert "0 mismatches" in out.stdout
@@ -660,6 +666,7 @@ def test_parts_assemble_to_the_full_image(R, ctx, variant, nparts):
     ps = R.prepare_scene(h, w, ctx.irreg())
     want, _ = _oracle("irreg").render(h, w)
     image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
     for p in range(nparts):
         rows = R.part_rows(h, p, nparts)
         part = torch.empty((max(rows, 1), w), dtype=torch.int32, device="cuda")
@@ -844,6 +851,7 @@ def test_batch_of_frames_in_one_launch(R, variant):
     stride = h * w + 40
     for rep in range(3):
         out = torch.full((n, stride), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
         R.render_batch_into(out.data_ptr(), h, w, ps, n, frame_stride=stride)
         ctx.sync()
         got = out.cpu().numpy()
@@ -854,6 +862,7 @@ def test_batch_of_frames_in_one_launch(R, variant):
     base = ps.camera()
     cams = np.stack([base + np.float32(0.37 * f) * np.array([1, 0, 0] * 1 + [0] * 9, np.float32) for f in range(n)])
     out = torch.zeros((n, h * w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
     R.render_batch_into(out.data_ptr(), h, w, ps, n, cams=cams)
     ctx.sync()
     got = out.cpu().numpy()
@@ -862,8 +871,10 @@ def test_batch_of_frames_in_one_launch(R, variant):
     # part 1 of 3 of every frame
     rows = R.part_rows(h, 1, 3)
     out = torch.zeros((n, rows * w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
     R.render_batch_into(out.data_ptr(), h, w, ps, n, part=1, nparts=3)
     one = torch.zeros((rows, w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
     R.render_into(one.data_ptr(), h, w, ps, part=1, nparts=3)
     ctx.sync()
     for f in range(n):
@@ -1197,6 +1208,7 @@ def test_odd_rows_per_tile_on_the_non_pooled_families(R, ctx, variant):
     ps = R.prepare_scene(h, w, ctx.irreg())
     want, _ = _oracle("irreg").render(h, w)
     image = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the render on the context's own: order them)
     for p in range(nparts):
         rows = R.part_rows(h, p, nparts, rows_per_tile=rpt)
         part = torch.empty((max(rows, 1), w), dtype=torch.int32, device="cuda")
