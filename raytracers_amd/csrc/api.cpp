@@ -413,6 +413,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
+  p.look_max = ctx->look_max > 0 ? ctx->look_max : ((nframes > 1 || p.nchunks > 32768) ? 32 : 64);
   p.tl_log2 = ps->tl_depth;
   p.solo = ctx->solo;
   if (pl.variant == RT_VARIANT_POOLED) {
@@ -669,6 +670,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->adaptive_order = v;
   } else if (k == "box2") {
     ctx->box2 = v != 0;
+  } else if (k == "look_max") {
+    ctx->look_max = std::max(0, std::min(64, v));
   } else if (k == "handover") {
     ctx->handover = v != 0;
   } else if (k == "solo") {
@@ -1172,6 +1175,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
+  p.look_max = ctx->look_max > 0 ? ctx->look_max : (p.nchunks > 32768 ? 32 : 64);
   p.tl_log2 = ps->tl_depth;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;

@@ -193,6 +193,7 @@ struct KParams {
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
   int cold;              // pooled family: > 0 = the COLD instantiation: a wave that cannot refill hands its last `cold` rays to the solo loop from inside the pooled loop
+  int look_max;          // pooled family: a wave with this many box items or more does not look at finished folds / vacant slots (64: it looks whenever it has less than a full batch)
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)
   int solo;              // pooled family: single-pixel tickets (deep_split == 6) are traced by solo_trace in a PROLOGUE ahead of the pooled loop (the SOLO instantiation; 0: off).  The hand-over of a wave's last rays from INSIDE the loop is `cold`, below
   int tl_log2;           // levels per treelet of the traversal copy (treelet.h; the masks in nodes64)

@@ -511,7 +511,7 @@ def test_work_counters_match_oracle(R, ctx, scene, h):
 @pytest.mark.parametrize("opts", [
     dict(waves_per_wg=4, wgs_per_cu=4), dict(waves_per_wg=16, wgs_per_cu=1), dict(thr_shade=1, thr_leaf=1),
     dict(thr_shade=64, thr_leaf=64), dict(lmax=2), dict(lmax=16), dict(lds_scene_bytes=0),
-    dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192),
+    dict(lds_scene_bytes=4096), dict(lds_sph_first=1, lds_scene_bytes=8192), dict(look_max=1), dict(look_max=32, thr_shade=8),
 ])
 @pytest.mark.parametrize("variant", [2, 3])
 def test_persistent_knobs_do_not_change_pixels(R, opts, variant):

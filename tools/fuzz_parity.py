@@ -66,7 +66,7 @@ while time.time() < t_end:
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
                  treelet=int(rng.choice([2, 2, 2, 1, 4])),
                  # a view's first frame at a small size: the COLD instantiation (in-loop hand-over to the solo loop)
-                 handover=int(rng.choice([0, 1, 1])))
+                 handover=int(rng.choice([0, 1, 1])), look_max=int(rng.choice([0, 0, 1, 16, 32, 64])))
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):

@@ -10,4 +10,23 @@ timeout 400 python tools/scale_prediction.py 20 > $OUT/scale_prediction.json 2> 
 tail -4 $OUT/scale_prediction.err
 timeout 170 python tools/fuzz_parity.py 150 101 > $OUT/fuzz_small_final.txt 2>&1; tail -1 $OUT/fuzz_small_final.txt
 timeout 170 python tools/fuzz_parity.py 150 201 700 300000 > $OUT/fuzz_large_final.txt 2>&1; tail -1 $OUT/fuzz_large_final.txt
+bash tools/gpu_ab.sh r04/look_max_ab <<'AB'
+new|rgbbox|1000|-r 20|look_max=64
+new|rgbbox|1000|-r 20|look_max=32
+new|irreg|1000|-r 20|look_max=64
+new|irreg|1000|-r 20|look_max=32
+new|rgbbox|1000|-r 0 -B 20|look_max=64
+new|rgbbox|1000|-r 0 -B 20|look_max=32
+new|irreg|1000|-r 0 -B 20|look_max=64
+new|irreg|1000|-r 0 -B 20|look_max=32
+new|irreg|4000|-r 5|look_max=64
+new|irreg|4000|-r 5|look_max=32
+new|big|2000|-r 4|look_max=64
+new|big|2000|-r 4|look_max=32
+new|irreg|2000|-r 8|look_max=64
+new|irreg|2000|-r 8|look_max=32
+base|rgbbox|1000|-r 0 -B 20|
+base|irreg|1000|-r 0 -B 20|
+AB
+timeout 100 python tools/part_probe.py irreg 4000 8 "look_max=64" "look_max=32" 2>&1 | grep -v amdgpu > $OUT/part_probe_look_max.txt
 echo r04 round done
