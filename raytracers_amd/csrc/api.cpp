@@ -413,7 +413,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
-  p.look_max = ctx->look_max > 0 ? ctx->look_max : ((nframes > 1 || p.nchunks > 32768) ? 32 : 64);
+  // (batches, and launches of more than 16 384 tiles -- frames beyond 1000 x 1000 and a rank's share of a 4000 x 4000 one: -1.8 .. -3.6 %
+  // with 32, profiles/r04/exp/e10, e11; a 1000 x 1000 frame is the same within +-1 % either way and keeps 64)
+  p.look_max = ctx->look_max > 0 ? ctx->look_max : ((nframes > 1 || p.nchunks > 16384) ? 32 : 64);
   p.tl_log2 = ps->tl_depth;
   p.solo = ctx->solo;
   if (pl.variant == RT_VARIANT_POOLED) {
@@ -1175,7 +1177,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
-  p.look_max = ctx->look_max > 0 ? ctx->look_max : (p.nchunks > 32768 ? 32 : 64);
+  p.look_max = ctx->look_max > 0 ? ctx->look_max : (p.nchunks > 16384 ? 32 : 64);
   p.tl_log2 = ps->tl_depth;
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;

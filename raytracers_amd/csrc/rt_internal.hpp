@@ -34,7 +34,7 @@ struct rt_context {
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
   int handover = 1;         // pooled family: single frames of ~360 x 360 .. 800 x 800 pixels are rendered by the COLD instantiation: a wave that cannot refill hands its last ray(s) to the solo loop from inside the pooled loop (0: the ordinary kernels)
-  int look_max = 0;         // pooled family: box-stack size from which a wave skips the look at finished folds (0 = auto: 32 for batches and frames of more than 32 768 tiles, 64 otherwise; 1 .. 64)
+  int look_max = 0;         // pooled family: box-stack size from which a wave skips the look at finished folds (0 = auto: 32 for batches and launches of more than 16 384 tiles, 64 otherwise; 1 .. 64)
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
   int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)
