@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e2, e3.  The options `wide` and `scout` of that day's library no longer exist: see the *_as_measured.patch files.)
 # Round 4, second GPU call: the WIDE and COLD instantiations -- parity first, then A/B.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e4.  The in-launch scout is not in the product: scout_in_launch_hot_list_as_measured.patch.)
 # Round 4, third GPU call: the in-launch scout (COLD instantiation): parity, then cold-frame timings.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

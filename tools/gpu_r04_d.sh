@@ -1,4 +1,6 @@
 #!/bin/bash
+# Round 4, debug call of the in-launch scout: the hot list's word and the device-side counters after a first frame
+# (-> profiles/r04/exp/e5; needs the library of scout_in_launch_hot_list_as_measured.patch built with -DRT_COLD_COUNTERS)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r04d

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e6.  `cold_first` / `cold_hold_depth` were that day's names; the product's option is `handover`.)
 # Round 4: the COLD instantiation without scouts (dynamic hold + in-loop solo hand-over): parity, then first-frame timings.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

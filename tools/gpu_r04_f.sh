@@ -1,4 +1,5 @@
 #!/bin/bash
+# Round 4: first frames at 500 / 700 / 1400: every workgroup vs the COLD instantiation (-> profiles/r04/exp/e7; option names of that day)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r04f

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e8; `cold_warm` / `cold_rays` were experiment knobs: the product hands over 1 ray in a first frame, 3 in an ordered one)
 # Round 4: the in-loop hand-over to the solo loop for ORDERED single frames (cold_warm=1), 1 .. 4 rays
 cd "$(dirname "$0")/.."
 OUT=$PWD/gpurun_out/r04g

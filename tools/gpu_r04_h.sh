@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e2_wide_fetch_pmc_mem.txt)
 # Round 4: the vector-memory counters of the quad-coalesced record fetch (the library of commit c263347, build/lib_wide) on the
 # 10^6-sphere frame and on irreg's batch launch, against the same library with wide=0 -- the counters behind the dead end e2.
 cd "$(dirname "$0")/.."

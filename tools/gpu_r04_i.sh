@@ -1,4 +1,5 @@
 #!/bin/bash
+# (-> profiles/r04/exp/e10; build/lib_look* = render_kernels.hip with the look restricted at compile time)
 # Round 4: VERDICT r3 item 5's "skip the look at finished folds while the box stack still holds >= 32 items": variants of the
 # library with the look restricted to nbox < 16 / 32 / 48 (build/lib_look*), against the product, through the native bench
 cd "$(dirname "$0")/.."
