@@ -60,6 +60,8 @@ sys.path.insert(0, ROOT)
 # largely serialise.  With MORE than ~20 queues actually busy the hardware scheduler
 # oversubscribes.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+# one process per GPU: RCCL and the IPC mapping of rank 0's images (the direct-store exchange) need the dmabuf IPC mode on this driver
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 NUM_SIMD = 256 * 4
