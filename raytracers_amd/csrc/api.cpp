@@ -481,13 +481,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       if (!to->valid && nframes == 1 && ctx->adaptive_order == 1 && ctx->deep_class < 0 && ctx->grid_div == 0 && p.nchunks <= 32768) {
         dp.sparse = true;
       }
-      // Small single frames (2 048 .. 10 000 tiles), ordered or not, are what their last bounce chains take: the COLD instantiation
-      // hands a wave's last ray (a first frame) or last three (an ordered one) to the solo loop from inside the pooled loop --
-      // rgbbox 500 x 500: first frame 0.395 -> 0.333 ms, later frames 0.280 -> 0.225; neutral to +2 % from 1000 x 1000 on, where it
-      // is not used (profiles/r04/exp/e7, e8).
-      if (ctx->handover && nframes == 1 && p.nchunks >= 2048 && p.nchunks <= 10000 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
+      // Small ORDERED single frames (2 048 .. 10 000 tiles) are what their last bounce chains take: the COLD instantiation hands a
+      // wave's last three rays to the solo loop from inside the pooled loop -- rgbbox 500 x 500 0.280 -> 0.225 ms; neutral to +2 %
+      // from 1000 x 1000 on, where it is not used (profiles/r04/exp/e7, e8).
+      if (ctx->handover && nframes == 1 && to->valid && p.nchunks >= 2048 && p.nchunks <= 10000 && max_depth > 4 && pl.waves == 16 && ctx->solo &&
           ps->tl_depth == rtk::kTreeletDepth && ctx->deep_class < 0 && ctx->adaptive_order == 1)
-        p.cold = to->valid ? 3 : 1;
+        p.cold = 3;
       p.deep_class = dp.deep_class;
       p.deep_split = dp.deep_split;
       p.deep_cap_log2 = dp.cap_log2;
@@ -499,6 +498,18 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         const int il = ns > 1 && xq == 2;
         if ((il ? 1 : ns) == order_shards) { p.nshards = ns; p.interleave = il; }
       }
+    }
+    // An UNORDERED single frame (a view's first; every frame when adaptive_order is 0) ends long after its first waves have run
+    // dry -- its long chains start whenever the raster reaches them.  The DONATE instantiation: a wave that cannot refill gives
+    // the rays it is left with, at a bounce boundary, to sibling waves of its workgroup that have left the loop and wait, one ray
+    // each, walked in the solo loop (LDS mailboxes, workgroup-scope atomics only).  First frames, profiles/r04/exp/e13: irreg
+    // 500 x 500 0.487 -> 0.402 ms, 1000 x 1000 0.591 -> 0.507, a rank's eighth of 4000 x 4000 0.83 / 0.93 -> 0.73 / 0.78, the
+    // 10^6-sphere frame 1.78 -> 1.52, rgbbox 1000 x 1000 0.587 -> 0.559; ordered frames do not gain (within 1 % at every size)
+    // and keep their kernels.  handover=2 (testing): every single frame, a wave offers its rays when it holds <= donate_max.
+    if (nframes == 1 && max_depth > 4 && pl.waves == 16 && ctx->solo && ps->tl_depth == rtk::kTreeletDepth &&
+        (ctx->handover == 2 || (ctx->handover == 1 && p.order == nullptr))) {
+      p.cold = 0;
+      p.donate = ctx->handover == 2 ? ctx->donate_max : 64;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
@@ -675,7 +686,9 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   } else if (k == "look_max") {
     ctx->look_max = std::max(0, std::min(64, v));
   } else if (k == "handover") {
-    ctx->handover = v != 0;
+    ctx->handover = std::max(0, std::min(2, v));
+  } else if (k == "donate_max") {
+    ctx->donate_max = std::max(1, std::min(64, v));
   } else if (k == "solo") {
     ctx->solo = v != 0;
   } else if (k == "treelet") {

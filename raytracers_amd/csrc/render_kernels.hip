@@ -378,7 +378,8 @@ __device__ __forceinline__ float pull(int lane_byte, float v) {   // v of the la
 // general machinery: ~5 traversal operations + LEAF + SHADE per bounce at 1700-3900 shader cycles each = ~7 us per bounce
 // (profiles/r03/exp/e10_trace.txt).  solo_trace finishes ONE pixel with the whole wave behind it -- called from the SOLO
 // instantiation's prologue for single-pixel tickets (the deepest tiles of an ordered view, all of them first tickets) and, in
-// the COLD instantiation, from inside the loop for the last rays of a wave that cannot refill.  The ray lives in registers (the
+// the COLD instantiation, from inside the loop for the last rays of a wave that cannot refill, and in the DONATE instantiation behind
+// the loop for rays given away by sibling waves.  The ray lives in registers (the
 // same value in every lane), the fold is
 // a loop of TREELET operations -- 2^D lanes per popped treelet root, every lane tests the boxes of both children of one
 // node of the treelet speculatively, a node counts iff the boxes on its path inside the treelet passed (treelet.h: the
@@ -528,9 +529,18 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // rays, all at a bounce boundary, hands them to solo_trace one after the other from INSIDE the loop.  The call costs this
 // instantiation 4-7 % in every regime -- which is why the kernels of larger frames and batches do not have
 // it -- and a small frame gets it back: rgbbox 500 x 500, first frame 0.395 -> 0.333 ms (one ray), later frames 0.280 -> 0.225
-// (three); at 1000 x 1000 it is neutral to +2 % (profiles/r04/exp/e7, e8).
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, bool COLD = false>
+// (three); at 1000 x 1000 it is neutral to +2 % (profiles/r04/exp/e7, e8).  (TAIL == 1)
+// DONATE (TAIL == 2): the instantiation for UNORDERED single frames (a view's first).  Their long chains start whenever the raster
+// reaches them, so the launch drains for a long time after the first waves have run dry (rgbbox 1000 x 1000: the queue is empty
+// at 0.6 of the span).  A wave that has left the pooled loop does not end: it offers itself in a workgroup word and sleeps; a
+// wave that cannot refill and stands at a bounce boundary gives its rays, one each, to the waves on offer (the ray's 12 dwords
+// into the waiting wave's idle ray table, then its inbox flag); the receiver walks the chain in solo_trace -- 2.5-4.5 us per
+// bounce instead of 7-16 -- and offers itself again.  Everything is LDS and workgroup scope (the hand-over through device
+// memory of round 3 failed on device-scope coherence); the only code inside the loop is the donor's block in SHADE, the call sits
+// behind the loop.  First frames -5 .. -17 %, ordered frames unchanged -- they keep their kernels (profiles/r04/exp/e13).
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
+  constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -555,6 +565,11 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // Zero the wave's region: lanes without an item read a stale entry and compute on it with
   // their results masked off, so every stale entry must decode to valid indices.
   for (int i = lane; i < per_wave_dw; i += 64) wbase[i] = 0u;
+  // DONATE: two words of the workgroup in wave 0's spare dump dwords -- [0] the waves that wait for a ray (bit = wave), [1] the
+  // waves that are still in the pooled loop -- and every wave's own inbox flag in its dump[3]; the inbox itself is the first
+  // three float4 of the waiting wave's ray table
+  unsigned *const wg_words = reinterpret_cast<unsigned *>(smem + sph_base + p.lds_sph) + 193;
+  if (DONATE && threadIdx.x == 0) wg_words[1] = THREADS / 64;
   __syncthreads();
   wkey[lane] = kKeyInit;
 
@@ -841,6 +856,40 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               root = false;
             }
           }
+          if constexpr (DONATE) {
+            // A wave that cannot refill and stands with a few rays at a bounce boundary (both lists empty) gives them to sibling
+            // waves of its workgroup that have left the loop and wait: each then walks its chain in the solo loop.  LDS only.
+            if ((hold || exhausted) && nbox == 0 && p.donate > 0 && p.tl_log2 == kTreeletDepth) {
+              unsigned long long m_l = bal(pix >= 0);
+              if (m_l != 0ull && (int)__popcll(m_l) <= p.donate && bal(root) == m_l) {
+                unsigned idle = (unsigned)uni((int)__hip_atomic_load(&wg_words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                while (m_l != 0ull && idle != 0u) {
+                  const int w = uni((int)__builtin_ctz(idle));
+                  unsigned old = 0u;
+                  if (lane == 0) old = __hip_atomic_fetch_and(&wg_words[0], ~(1u << w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+                  idle = old & ~(1u << w);
+                  if ((old >> w) & 1u) {       // the wave is ours: fill its inbox
+                    const int src = uni((int)__builtin_ctzll(m_l));
+                    m_l &= m_l - 1ull;
+                    unsigned *const ob = wbase + (w - wave) * per_wave_dw;
+                    float4 *const ib = reinterpret_cast<float4 *>(ob + kPooledWaveFixedDw);
+                    if (lane == src) {
+                      ib[0] = make_float4(r.ox, r.oy, r.oz, r.dx);
+                      ib[1] = make_float4(r.dy, r.dz, lr, lg);
+                      ib[2] = make_float4(lb, __int_as_float(pix), __int_as_float(depth), __int_as_float(ptile));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == src) {
+                      __hip_atomic_store(&ob[195], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                      pix = -1;
+                      root = false;
+                    }
+                  }
+                }
+              }
+            }
+          }
           // A new fold starts with the ROOT's box test (items are nodes whose own box passed).
           if (root) ray_derive(r);   // one place for both scattered and primary rays
           const bool root_hit = root && box_hit(r, p.root_lo[0], p.root_lo[1], p.root_lo[2], p.root_hi[0], p.root_hi[1], p.root_hi[2]);
@@ -1062,6 +1111,39 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         if (tr_kind == 0) tr_cyc[0] += dt;
         else if (tr_kind == 1) { tr_cyc[1] += dt; tr_nb2++; }
         else tr_cyc[2] += dt;
+      }
+    }
+  }
+  if constexpr (DONATE) {
+    // This wave is finished: it waits for rays of its siblings until every wave of the workgroup has left the loop.
+    if (p.donate > 0 && p.tl_log2 == kTreeletDepth) {
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&wg_words[1], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bool offered = false;
+      for (;;) {      // (ends: every wave of the workgroup leaves the pooled loop, and decrements the count when it does)
+        if (!offered) {
+          if (lane == 0) __hip_atomic_fetch_or(&wg_words[0], 1u << wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          offered = true;
+        }
+        // the count first, the flag second: a donor fills the inbox before it leaves the loop itself
+        const unsigned active = (unsigned)uni((int)__hip_atomic_load(&wg_words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned full = (unsigned)uni((int)__hip_atomic_load(&wbase[195], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (full != 0u) {
+          const float4 a = wray[0], b = wray[1], c = wray[2];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          if (lane == 0) __hip_atomic_store(&wbase[195], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          offered = false;
+          __builtin_amdgcn_s_setprio(2);      // (a ray that arrives here is one of the workgroup's last)
+          solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, a.x, a.y, a.z, a.w,
+                     b.x, b.y, b.z, b.w, c.x, __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
+          __builtin_amdgcn_s_setprio(0);
+          continue;
+        }
+        if (active == 0u) break;
+        __builtin_amdgcn_s_sleep(16);
       }
     }
   }
@@ -1334,10 +1416,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, bool COLD = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, COLD>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1351,8 +1433,11 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
   // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
   if (p.cold && waves_per_wg == 16)
-    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, true>(p, grid, stream) : launch_pooled_t<1024, true, false, false, true>(p, grid, stream))
-                   : (solo ? launch_pooled_t<1024, false, false, true, true>(p, grid, stream) : launch_pooled_t<1024, false, false, false, true>(p, grid, stream));
+    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, 1>(p, grid, stream) : launch_pooled_t<1024, true, false, false, 1>(p, grid, stream))
+                   : (solo ? launch_pooled_t<1024, false, false, true, 1>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 1>(p, grid, stream));
+  if (p.donate && waves_per_wg == 16)
+    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, 2>(p, grid, stream) : launch_pooled_t<1024, true, false, false, 2>(p, grid, stream))
+                   : (solo ? launch_pooled_t<1024, false, false, true, 2>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 2>(p, grid, stream));
 #define RT_POOLED_CASE(W)                                                                                               \
   case W:                                                                                                               \
     return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \
@@ -1376,8 +1461,12 @@ void warm_render_kernels() {
   // (the instantiations a view's first frames and its policy may switch to: a first use inside somebody's timed loop is 0.2-0.3 ms)
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true>);
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, true>);
-  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 1>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 1>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 2>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 2>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2>);
   (void)hipFuncGetAttributes(&a, (const void *)tile_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_place_kernel);

@@ -192,6 +192,7 @@ struct KParams {
   int ray_planes;        // ray table: 3 = {o, a} {1/d} {d} per slot; 2 = without {d} (LEAF then pulls d with ds_bpermute: 1 KB per wave less)
   int prio_depth;        // bounce depth at which a wave raises its issue priority (0: never)
   const int *order;      // [order_table_ints(nchunks)] position -> tile (nullptr: the strips in row-major order), then the shards' class tables
+  int donate;            // pooled family: > 0 = the DONATE instantiation: a wave that cannot refill and holds at most `donate` rays gives them to waiting sibling waves of its workgroup
   int cold;              // pooled family: > 0 = the COLD instantiation: a wave that cannot refill hands its last `cold` rays to the solo loop from inside the pooled loop
   int look_max;          // pooled family: a wave with this many box items or more does not look at finished folds / vacant slots (64: it looks whenever it has less than a full batch)
   int box2;              // pooled family: a wave with <= 32 box items runs the two-level BOX2 operation (0: off)

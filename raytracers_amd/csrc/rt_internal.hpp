@@ -33,7 +33,8 @@ struct rt_context {
   int lmax = 8;             // deferred-leaf capacity per lane
   int lds_scene_bytes = -1; // < 0: as much as fits
   int lds_sph_first = 0;    // stage spheres before nodes when LDS is short
-  int handover = 1;         // pooled family: single frames of ~360 x 360 .. 800 x 800 pixels are rendered by the COLD instantiation: a wave that cannot refill hands its last ray(s) to the solo loop from inside the pooled loop (0: the ordinary kernels)
+  int handover = 1;         // pooled family, single frames: 1 = an unordered frame (a view's first) is rendered by the DONATE instantiation (a wave that cannot refill gives its rays to waiting sibling waves, LDS mailboxes), an ordered one of ~360 x 360 .. 800 x 800 pixels by the COLD instantiation (a wave's last rays go to the solo loop from inside the pooled loop); 0 = the ordinary kernels; 2 (testing) = DONATE for every single frame
+  int donate_max = 64;      // handover == 2: a wave offers its rays when it holds at most this many
   int look_max = 0;         // pooled family: box-stack size from which a wave skips the look at finished folds (0 = auto: 32 for batches and launches of more than 16 384 tiles, 64 otherwise; 1 .. 64)
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop

@@ -228,12 +228,15 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(handover=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
-                                  dict(xcd_queues=0, thr_shade=64)])
+                                  dict(xcd_queues=0, thr_shade=64), dict(handover=2, donate_max=1), dict(handover=2, donate_max=64),
+                                  dict(handover=2, donate_max=8, thr_shade=8), dict(handover=2, donate_max=64, grid_div=4)])
 def test_first_frames_of_new_views(R, opts):
-    """A view's FIRST frame (no tile order yet) runs on every workgroup and, at small sizes, through the COLD instantiation (a
-    wave that cannot refill hands its last ray to the solo loop from INSIDE the pooled loop): the pixels of the frame are
-    the oracle's, on both scenes and a random one, at sizes on either side of the range the instantiation is used for;
-    every frame is a new view (fresh prepared scenes and a camera path), into a poisoned buffer."""
+    """A view's FIRST frame (no tile order yet) runs on every workgroup, through the DONATE instantiation (a wave that cannot
+    refill gives its rays to sibling waves of its workgroup that have left the loop; each walks its ray in the solo loop);
+    small ORDERED frames through the COLD one (a wave's last rays go to the solo loop from INSIDE the pooled loop);
+    handover=2 donates in every single frame.  The pixels are the oracle's, on both scenes and a random one, at sizes on
+    either side of the range COLD is used for; every first frame is a new view (fresh prepared scenes and a camera path),
+    into a poisoned buffer."""
     import bench
     import torch
     c = R.Context()

@@ -65,8 +65,12 @@ while time.time() < t_end:
                  static_first=int(rng.choice([0, 1, 1])),
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
                  treelet=int(rng.choice([2, 2, 2, 1, 4])),
-                 # a view's first frame at a small size: the COLD instantiation (in-loop hand-over to the solo loop)
-                 handover=int(rng.choice([0, 1, 1])), look_max=int(rng.choice([0, 0, 1, 16, 32, 64])))
+                 # the tails of single frames: 1 = DONATE for unordered frames (rays of waves that cannot refill go to waiting sibling
+                 # waves) and COLD for small ordered ones (in-loop hand-over to the solo loop), 2 = DONATE for every single frame
+                 handover=int(rng.choice([0, 1, 1, 2, 2])), donate_max=int(rng.choice([1, 4, 64])), look_max=int(rng.choice([0, 0, 1, 16, 32, 64])))
+    for kv in os.environ.get("FUZZ_FORCE", "").split(","):     # e.g. FUZZ_FORCE=handover=2,donate_max=8: knobs pinned for an experiment
+        if kv:
+            knobs[kv.split("=")[0]] = int(kv.split("=")[1])
     for k, v in knobs.items():
         ctx.set_option(k, v)
     for gpu_build in (1, 0):

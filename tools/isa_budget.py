@@ -14,10 +14,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "raytracers_amd", "csrc", "render_kernels.hip")
-DEFAULT = ["pooled_kernelILi1024ELb1ELb0ELb0ELb0E", "pooled_kernelILi1024ELb0ELb0ELb0ELb0E"]
-NAMES = {"pooled_kernelILi1024ELb1ELb0ELb0ELb0E": "pooled_kernel<1024, ALL_LDS> (rgbbox: the whole scene in LDS)",
-         "pooled_kernelILi1024ELb0ELb0ELb0ELb0E": "pooled_kernel<1024> (irreg, 10^6 spheres: node prefix in LDS, the rest through buffer_load)",
-         "pooled_kernelILi1024ELb0ELb0ELb0ELb1E": "pooled_kernel<1024, COLD> (the first frame of a view)"}
+DEFAULT = ["pooled_kernelILi1024ELb1ELb0ELb0ELi0E", "pooled_kernelILi1024ELb0ELb0ELb0ELi0E"]
+NAMES = {"pooled_kernelILi1024ELb1ELb0ELb0ELi0E": "pooled_kernel<1024, ALL_LDS> (rgbbox: the whole scene in LDS)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi0E": "pooled_kernel<1024> (irreg, 10^6 spheres: node prefix in LDS, the rest through buffer_load)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi1E": "pooled_kernel<1024, COLD> (small ordered frames)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi2E": "pooled_kernel<1024, DONATE> (unordered frames)"}
 
 FP32 = re.compile(r"^v_(add|sub|subrev|mul|fma|mac|fmac|mad)_(f32|legacy_f32)|^v_pk_(add|mul|fma)_f32")
 SEL = re.compile(r"^v_(cndmask|min|max|min3|max3|med3|cmp|cmpx)")

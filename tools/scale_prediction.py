@@ -47,13 +47,16 @@ def timed(fn, reps=5, warm=3, sync_each=False):
     for _ in range(warm + 1):        # (render + sync: a view's deep-tile policy reaches the host asynchronously)
         fn()
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-        if sync_each:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    return 1e6 * (time.perf_counter() - t0) / reps
+    groups = []
+    for _ in range(3):               # (the median of three groups: one host hiccup in one part would otherwise be "the slowest rank")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        groups.append(1e6 * (time.perf_counter() - t0) / reps)
+    return sorted(groups)[1]
 
 
 def assemble_us(pr, h, w, W, nb):
