@@ -59,12 +59,17 @@ build/queue_check: tools/queue_check.cpp $(CSRC)/rt_device.hpp $(CSRC)/lane_core
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Wall -I$(CSRC) -o $@ $<
 
+# the DONATE instantiation's mailbox protocol (render_kernels.hip) as a model, random interleavings; in the CPU test suite
+build/donate_check: tools/donate_check.cpp
+	@mkdir -p build
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -o $@ $<
+
 # design tool + CPU check of the treelet numbering / masks (treelet.h) against a plain depth-first walk; in the CPU test suite
 build/treelet_probe: tools/treelet_probe.cpp $(CSRC)/lane_core.h $(CSRC)/treelet.h $(CSRC)/rt_host.hpp $(OBJ)/host_build.o
 	@mkdir -p build
 	$(CXX) $(HOSTFLAGS) -I$(CSRC) -o $@ tools/treelet_probe.cpp $(OBJ)/host_build.o
 
-tools: build/rtbench build/issue_peak build/queue_check build/treelet_probe build/hip_touch
+tools: build/rtbench build/issue_peak build/queue_check build/donate_check build/treelet_probe build/hip_touch
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -120,6 +120,22 @@ def test_tile_queue_protocol_on_the_cpu():
         assert "random cases" in out.stdout and "passed" in out.stdout
 
 
+def test_ray_donation_protocol_on_the_cpu():
+    """tools/donate_check plays the mailbox protocol of the pooled kernel's DONATE instantiation (waves that have left the
+    loop offer themselves in a workgroup word; waves that cannot refill give them one ray each through their idle ray
+    tables) as a model, one LDS operation per step, in random interleavings: every ray is finished exactly once, no inbox
+    is overwritten or read half-written, no ray goes to a wave that has ended, every wave ends.  The checker must also
+    catch the two orderings the kernel's comments insist on when they are broken (count before flag; ray before flag)."""
+    exe = os.path.join(ROOT, "build", "donate_check")
+    subprocess.run(["make", "-s", "build/donate_check"], cwd=ROOT, check=True)
+    for seed in (1, 2, 3):
+        out = subprocess.run([exe, "20000", str(seed)], capture_output=True, text=True)
+        assert out.returncode == 0 and "protocol holds" in out.stdout, out.stdout + out.stderr
+    for mutate in (1, 2):
+        out = subprocess.run([exe, "20000", "1", str(mutate)], capture_output=True, text=True)
+        assert out.returncode != 0 and "FAILED" in out.stdout, (mutate, out.stdout)
+
+
 @pytest.mark.parametrize("scene,size", [("rgbbox", "96"), ("irreg", "96"), ("23", "64")])
 def test_treelet_numbering_and_masks_on_the_cpu(scene, size):
     """tools/treelet_probe redoes every fold of a small frame from the 64-byte records of the traversal copy cut into
