@@ -502,9 +502,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     // An UNORDERED single frame (a view's first; every frame when adaptive_order is 0) ends long after its first waves have run
     // dry -- its long chains start whenever the raster reaches them.  The DONATE instantiation: a wave that cannot refill gives
     // the rays it is left with, at a bounce boundary, to sibling waves of its workgroup that have left the loop and wait, one ray
-    // each, walked in the solo loop (LDS mailboxes, workgroup-scope atomics only).  First frames, profiles/r04/exp/e13: irreg
-    // 500 x 500 0.487 -> 0.402 ms, 1000 x 1000 0.591 -> 0.507, a rank's eighth of 4000 x 4000 0.83 / 0.93 -> 0.73 / 0.78, the
-    // 10^6-sphere frame 1.78 -> 1.52, rgbbox 1000 x 1000 0.587 -> 0.559; ordered frames do not gain (within 1 % at every size)
+    // each, walked in the solo loop (LDS mailboxes, workgroup-scope atomics only).  First frames, profiles/r04/exp/e13, e14: irreg
+    // 500 x 500 0.519 -> 0.373 ms, 1000 x 1000 0.588 -> 0.486, a rank's eighth of 4000 x 4000 0.83 / 0.92 -> 0.67 / 0.72, the
+    // 10^6-sphere frame 1.74 -> 1.50, rgbbox 1000 x 1000 0.617 -> 0.549; ordered frames do not gain (within 1 % at every size)
     // and keep their kernels.  handover=2 (testing): every single frame, a wave offers its rays when it holds <= donate_max.
     if (nframes == 1 && max_depth > 4 && pl.waves == 16 && ctx->solo && ps->tl_depth == rtk::kTreeletDepth &&
         (ctx->handover == 2 || (ctx->handover == 1 && p.order == nullptr))) {

@@ -533,11 +533,11 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // DONATE (TAIL == 2): the instantiation for UNORDERED single frames (a view's first).  Their long chains start whenever the raster
 // reaches them, so the launch drains for a long time after the first waves have run dry (rgbbox 1000 x 1000: the queue is empty
 // at 0.6 of the span).  A wave that has left the pooled loop does not end: it offers itself in a workgroup word and sleeps; a
-// wave that cannot refill and stands at a bounce boundary gives its rays, one each, to the waves on offer (the ray's 12 dwords
+// wave that cannot refill gives the rays it has just scattered, one each, to the waves on offer (the ray's 12 dwords
 // into the waiting wave's idle ray table, then its inbox flag); the receiver walks the chain in solo_trace -- 2.5-4.5 us per
 // bounce instead of 7-16 -- and offers itself again.  Everything is LDS and workgroup scope (the hand-over through device
 // memory of round 3 failed on device-scope coherence); the only code inside the loop is the donor's block in SHADE, the call sits
-// behind the loop.  First frames -5 .. -17 %, ordered frames unchanged -- they keep their kernels (profiles/r04/exp/e13).
+// behind the loop.  First frames -11 .. -28 %, ordered frames unchanged -- they keep their kernels (profiles/r04/exp/e13, e14).
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
@@ -857,11 +857,12 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             }
           }
           if constexpr (DONATE) {
-            // A wave that cannot refill and stands with a few rays at a bounce boundary (both lists empty) gives them to sibling
-            // waves of its workgroup that have left the loop and wait: each then walks its chain in the solo loop.  LDS only.
-            if ((hold || exhausted) && nbox == 0 && p.donate > 0 && p.tl_log2 == kTreeletDepth) {
-              unsigned long long m_l = bal(pix >= 0);
-              if (m_l != 0ull && (int)__popcll(m_l) <= p.donate && bal(root) == m_l) {
+            // A wave that cannot refill gives the rays that stand at a bounce boundary now (just scattered: their slots have no item
+            // left in either list, whatever the wave's other rays are doing) to sibling waves of its workgroup that have left the loop
+            // and wait: each then walks its chain in the solo loop.  LDS only.
+            if ((hold || exhausted) && p.donate > 0 && p.tl_log2 == kTreeletDepth) {
+              unsigned long long m_l = bal(root);
+              if (m_l != 0ull && (int)__popcll(bal(pix >= 0)) <= p.donate) {
                 unsigned idle = (unsigned)uni((int)__hip_atomic_load(&wg_words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 while (m_l != 0ull && idle != 0u) {
                   const int w = uni((int)__builtin_ctz(idle));
