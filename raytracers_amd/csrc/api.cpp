@@ -437,6 +437,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         // Measured useless on both scenes -- 0.64 / 0.63 ms per frame of a sliding camera against 0.68 / 0.74 without: which
         // tiles hold this frame's longest chains is as chaotic as the chains themselves, profiles/r03/exp/e25.)
         TileOrder o{};
+        // (pixel tickets: the per-pixel record and the pixel list of the view, if this context may use them)
+        const bool px_ok = ctx->pixel_order != 0 && w < 65536 && p.rows_local < 65536;
+        const size_t px_bytes = px_ok ? static_cast<size_t>(h) * static_cast<size_t>(w) : 0;
+        const size_t px_elems = px_ok ? static_cast<size_t>(p.rows_local) * static_cast<size_t>(p.w) : 0;
         if (ps->orders.size() >= 8) {
           size_t lru = 0;
           for (size_t i = 1; i < ps->orders.size(); ++i)
@@ -444,13 +448,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           TileOrder &v = ps->orders[lru];
           o.classes_event = v.classes_event;   // (a copy still in flight lands in the slot before any later one: same stream)
           o.classes_slot = v.classes_slot;
-          if (v.ntiles == p.nchunks) {
+          if (v.ntiles == p.nchunks && v.cost_px_bytes >= px_bytes && v.px_elems >= px_elems) {
             o.cost = v.cost;
             o.order = v.order;
+            o.cost_px = v.cost_px; o.cost_px_bytes = v.cost_px_bytes;
+            o.px_list = v.px_list; o.px_elems = v.px_elems;
           } else {
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipFree(v.cost);
             (void)hipFree(v.order);
+            (void)hipFree(v.cost_px);
+            (void)hipFree(v.px_list);
           }
           ps->orders.erase(ps->orders.begin() + static_cast<std::ptrdiff_t>(lru));
         }
@@ -462,6 +470,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
           RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(o.ntiles))));
         }
+        if (px_ok && !o.px_list) {
+          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost_px), px_bytes));
+          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.px_list), sizeof(unsigned) * (px_elems + rtk::kPxHdrInts)));
+          o.cost_px_bytes = px_bytes;
+          o.px_elems = px_elems;
+        }
         RT_HIP(ctx, hipMemsetAsync(o.cost, 0, sizeof(int) * static_cast<size_t>(o.ntiles), ctx->stream));
         ps->orders.push_back(o);
         to = &ps->orders.back();
@@ -470,8 +484,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // The record of a view is a deterministic function of the view, so the table is computed
       // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
       // recomputes every frame (testing aid).
-      const bool rerecord = !to->valid || ctx->adaptive_order == 2;
+      // (a view whose tiles were first recorded by a batch has no per-pixel record yet: its first single frame records again)
+      const bool px_can = ctx->pixel_order != 0 && nframes == 1 && to->px_list != nullptr && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
+                          to->cost_px_bytes >= static_cast<size_t>(h) * w && (p.nshards == 1 || p.interleave);
+      const bool rerecord = !to->valid || ctx->adaptive_order == 2 || (px_can && !to->px_valid);
       p.cost = rerecord ? to->cost : nullptr;
+      p.cost_px = rerecord && px_can ? to->cost_px : nullptr;
       p.order = to->valid ? to->order : nullptr;
       DeepPolicy dp;
       if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
@@ -499,6 +517,21 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         if ((il ? 1 : ns) == order_shards) { p.nshards = ns; p.interleave = il; }
       }
     }
+    // Pixel tickets (the ORD instantiation): an ordered single frame of a view that has its pixel list draws from it -- every
+    // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
+    if (to && to->valid && to->px_valid && nframes == 1 && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 &&
+        (p.nshards == 1 || p.interleave) && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
+        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4))) {
+      p.px_list = to->px_list;
+      p.px_hdr = reinterpret_cast<const int *>(to->px_list + to->px_elems);
+      p.px_hold = ctx->px_hold;
+      p.cold = 0;
+      if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
+        const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+        const int il = ns > 1 && xq == 2;
+        if (ns == 1 || il) { pl.grid = pl.grid_full; p.nshards = ns; p.interleave = il; }
+      }
+    }
     // An UNORDERED single frame (a view's first; every frame when adaptive_order is 0) ends long after its first waves have run
     // dry -- its long chains start whenever the raster reaches them.  The DONATE instantiation: a wave that cannot refill gives
     // the rays it is left with, at a bounce boundary, to sibling waves of its workgroup that have left the loop and wait, one ray
@@ -519,6 +552,15 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       to->valid = true;
       to->have_classes = false;
       if (int rc = request_classes(ctx, ps, to)) return rc;
+      if (p.cost_px) {
+        // ... and the view's pixel list from the per-pixel record
+        if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
+        const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, p.out_skip, p.tiles_x, p.tiles_y};
+        const int solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+        RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, ctx->px_thr, solo_cap, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems),
+                                         ctx->px_scratch, ctx->stream));
+        to->px_valid = true;
+      }
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
@@ -600,6 +642,7 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
+  if (ctx->px_scratch) (void)hipFree(ctx->px_scratch);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   if (ctx->arena) (void)hipFree(ctx->arena);
@@ -715,6 +758,14 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->tpt_log2 = v;
   } else if (k == "static_first") {
     ctx->static_first = v != 0;
+  } else if (k == "pixel_order") {
+    ctx->pixel_order = std::max(0, std::min(2, v));
+  } else if (k == "px_solo" || k == "px_w8" || k == "px_w16" || k == "px_w32") {
+    ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(1, std::min(255, v));
+  } else if (k == "px_hold") {
+    ctx->px_hold = v & 0x1f;
+  } else if (k == "px_solo_div") {
+    ctx->px_solo_div = std::max(1, std::min(4096, v));
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -903,6 +954,8 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   for (auto &o : ps->orders) {
     (void)hipFree(o.cost);
     (void)hipFree(o.order);
+    (void)hipFree(o.cost_px);
+    (void)hipFree(o.px_list);
     if (o.classes_event) (void)hipEventDestroy(o.classes_event);
   }
   if (ps->classes_pinned) (void)hipHostFree(ps->classes_pinned);

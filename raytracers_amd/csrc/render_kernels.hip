@@ -512,7 +512,10 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
     if (!shade_ray<false>(r, have, t, s.x, s.y, s.z, c.x, c.y, c.z, c.w, lr, lg, lb, depth, max_depth, &pixel)) {
       if (lane == 0) {
         pp->out[pix] = pixel;
-        if (pp->cost != nullptr && depth >= 2) atomicMax(&pp->cost[ptile], depth + 1);
+        if (pp->cost != nullptr) {
+          if (pp->cost_px != nullptr) pp->cost_px[pix] = (unsigned char)(depth < 254 ? depth + 1 : 255);
+          if (depth >= 2) atomicMax(&pp->cost[ptile], depth + 1);
+        }
       }
       return;
     }
@@ -538,9 +541,16 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // bounce instead of 7-16 -- and offers itself again.  Everything is LDS and workgroup scope (the hand-over through device
 // memory of round 3 failed on device-scope coherence); the only code inside the loop is the donor's block in SHADE, the call sits
 // behind the loop.  First frames -11 .. -28 %, ordered frames unchanged -- they keep their kernels (profiles/r04/exp/e13, e14).
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0>
+// ORD: the instantiation for ORDERED single frames whose queue runs over the view's PIXEL LIST (rt_device.hpp: pixel tickets) instead
+// of its tiles: pixels sorted by the length of their bounce chains, longest first; the longest go out one per ticket and are walked
+// by solo_trace in the prologue, the next ones 8 / 16 / 32 per ticket to waves that do not refill while they trace them, the bulk 64
+// per ticket.  A tile's 64 pixels mix one or two long chains with dozens of short ones, so a wave that holds a deep TILE parks most of
+// its slots, and one that does not walks the long chain at a full wave's cadence; a ticket of pixels with EQUAL chain lengths keeps
+// its wave exactly as full as the chain's deadline allows, and the last tickets of the queue are all one-ray pixels (no drain).
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
+  static_assert(!ORD || (SOLO && TAIL == 0 && !STATS), "ORD: the solo prologue, no tail variant");
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -610,7 +620,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     qc.ns_log2 = ns_log2; qc.tiles_x = p.tiles_x; qc.tiles_y = p.tiles_y; qc.nframes = p.nframes;
     qc.interleave = p.interleave;
     qc.ds = p.deep_split; qc.tpt = p.tpt_log2; qc.cap_log2 = p.deep_cap_log2; qc.ntiles = p.nchunks;
-    qc.order = deep_on ? p.order : nullptr; qc.deep_class = p.deep_class;
+    qc.order = (!ORD && deep_on) ? p.order : nullptr; qc.deep_class = p.deep_class;
+    qc.px = ORD ? p.px_hdr : nullptr;
     qc.home_waves = nwaves >> ns_log2;                       // the same for every shard (the grid is a multiple of nshards)
     qc.q_static = p.static_first ? qc.home_waves : 0u;
     return qc;
@@ -631,7 +642,42 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // of the pooled loop: a call inside the loop cost the whole kernel 4-7 % (registers saved around it, scalar spills).
   // (its own instantiation: with the call compiled in, the loop behind it runs 1-5 % slower -- scalar registers saved around
   // the call stay spilled -- so launches without single-pixel tickets use the kernel without it)
-  if (SOLO && deep_on && p.deep_split == 6 && p.tl_log2 == kTreeletDepth) {
+  unsigned q_cls = kPxClasses - 1;   // (ORD) class of the ticket in hand
+  if constexpr (ORD) {
+    // the wave's one-pixel tickets (all of them first tickets of the list: the longest chains of the view), each walked by the
+    // solo loop; the first ticket of another class goes to the pooled loop
+    const bool solo_ok = p.solo && p.tl_log2 == kTreeletDepth;
+    for (;;) {
+      TicketSpan sp;
+      const QueueConst qc = queue_const();
+      const unsigned wave_rank = (unsigned)uni((int)((unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2)));
+      const bool got = queue_draw(q_state, qc, wave_rank, [&](int shard) {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(&p.queue[kQueueStride * shard], 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane(v);
+      }, &sp);
+      if (!got) {
+        exhausted = true;
+        break;
+      }
+      if (sp.cls != 0u || !solo_ok) {
+        q_next = sp.q_next;
+        q_end = sp.q_end;
+        q_cls = sp.cls;
+        q_enter = true;
+        break;
+      }
+      const unsigned e = p.px_list[sp.q_next];      // uniform (scalar) load
+      const int col = (int)(e & 0xffffu), lrow = (int)(e >> 16);
+      const int k = lrow >> p.rpt_log2;
+      const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+      Ray pr;
+      primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
+      solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+                 pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, (lrow >> 3) * p.tiles_x + (col >> 3));
+    }
+  }
+  if (!ORD && SOLO && deep_on && p.deep_split == 6 && p.tl_log2 == kTreeletDepth) {
     for (;;) {
       TicketSpan sp;
       const QueueConst qc = queue_const();
@@ -739,15 +785,61 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               root = true;
             } else {
               p.out[pix] = pixel;
+              // cost record for the adaptive order: the longest bounce chain seen in the tile, and the pixel's own
+              if (p.cost != nullptr) {
+                if (p.cost_px != nullptr) p.cost_px[pix] = (unsigned char)(depth < 254 ? depth + 1 : 255);
+                if (depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
+              }
               pix = -1;
-              // cost record for the adaptive tile order: the longest bounce chain seen in the tile
-              if (p.cost != nullptr && depth >= 2) atomicMax(&p.cost[ptile], depth + 1);
             }
           }
           bool want = (pix < 0) & !exhausted & !hold;
           int slot = -1;
           unsigned long long m = bal(want);
-          while (m != 0ull) {            // wave-uniform loop
+          while (ORD && m != 0ull) {     // pixel tickets: the next pixels of the view's list
+            if (__builtin_expect(q_next == q_end, 0)) {
+              if (hold) break;           // a ticket of a held class is in flight: no further tickets for now
+              TicketSpan sp;
+              const QueueConst qc = queue_const();
+              const unsigned wave_rank = (unsigned)uni((int)((unsigned)wave * (gridDim.x >> ns_log2) + (blockIdx.x >> ns_log2)));
+              const bool got = queue_draw(q_state, qc, wave_rank, [&](int shard) {
+                unsigned v = 0;
+                if (lane == 0) v = atomicAdd(&p.queue[kQueueStride * shard], 1u);
+                return (unsigned)__builtin_amdgcn_readfirstlane(v);
+              }, &sp);
+              if (!got) {
+                exhausted = true;
+                break;
+              }
+              q_next = sp.q_next;
+              q_end = sp.q_end;
+              q_cls = sp.cls;
+              q_enter = true;
+            }
+            if (__builtin_expect(q_enter, 0)) {
+              q_enter = false;
+              if ((p.px_hold >> q_cls) & 1) {
+                hold = true;
+                __builtin_amdgcn_s_setprio(3);
+              }
+            }
+            const unsigned avail = q_end - q_next;
+            const unsigned rank = (unsigned)lane_rank(m);
+            const unsigned cnt = (unsigned)__popcll(m);
+            if (want & (rank < avail)) {
+              const unsigned e = p.px_list[q_next + rank];
+              const int col = (int)(e & 0xffffu), lrow = (int)(e >> 16);
+              const int k = lrow >> p.rpt_log2;
+              slot = lrow * p.w + col + k * p.out_skip;
+              ptile = (lrow >> 3) * p.tiles_x + (col >> 3);
+              const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+              primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
+              want = false;
+            }
+            q_next += (cnt < avail) ? cnt : avail;
+            m = bal(want);
+          }
+          while (!ORD && m != 0ull) {    // wave-uniform loop
             if (__builtin_expect(q_next == q_end, 0)) {   // (cold: the register allocator must not favour the draw's values over the hot loop's)
               if (hold) break;           // a deep tile is in flight: no further tickets for now
               // A ticket: 1 << tpt_log2 consecutive positions of a shard's segment (a batch launch and a large frame draw
@@ -1316,6 +1408,102 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 }
 
 // ---------------------------------------------------------------------------------
+// Pixel list of a view (rt_device.hpp: pixel tickets).  The view's first frame stores, next to every pixel, the number of
+// rays its chain took (p.cost_px, one byte, indexed like the framebuffer); these kernels turn that record into the list the
+// view's later single frames draw their tickets from: the part's pixels as (local row << 16 | column), sorted by chain length,
+// longest first (a counting sort over 64 bins; a workgroup's pixels of one bin stay together, so a ticket's pixels are
+// neighbours wherever a region has enough pixels of one length), and the header that cuts the list into the ticket classes.
+// Which pixel goes where changes the ORDER in which independent pixels are traced, nothing else.
+// ---------------------------------------------------------------------------------
+constexpr int kPxThreads = 256;
+constexpr int kPxBins = 64;
+__device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }   // bin = rays traced (saturating)
+
+// the workgroup's tiles [t0, t1): four tiles at a time, one pixel per thread; f(col, lrow, rays)
+template <class F>
+__device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
+  const int ntiles = g.tiles_x * g.tiles_y;
+  const int t0 = (int)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  for (int tb = t0; tb < t1; tb += kPxThreads / 64) {
+    const int tile = tb + ((int)threadIdx.x >> 6), within = (int)threadIdx.x & 63;
+    if (tile >= t1) continue;
+    const int ty = tile / g.tiles_x;
+    const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
+    if (col >= g.w || lrow >= g.rows_local) continue;
+    const size_t idx = (size_t)lrow * g.w + col + (size_t)(lrow >> g.rpt_log2) * (size_t)g.out_skip;
+    f(col, lrow, (int)cost_px[idx]);
+  }
+}
+// counts[bin * nblocks + block]
+__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int *counts) {
+  __shared__ int hist[kPxBins];
+  if (threadIdx.x < kPxBins) hist[threadIdx.x] = 0;
+  __syncthreads();
+  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays)], 1); });
+  __syncthreads();
+  if (threadIdx.x < kPxBins) counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length); the header
+__global__ __launch_bounds__(kPxThreads) void px_scan_kernel(int *counts, int nblocks, int thr0, int thr1, int thr2, int thr3, int solo_cap, int *hdr) {
+  __shared__ int part[kPxBins][kPxThreads / kPxBins + 1];
+  __shared__ int bin_start[kPxBins + 1];
+  constexpr int Q = kPxThreads / kPxBins;            // threads per bin: each scans a quarter of the blocks
+  const int bin = (int)threadIdx.x / Q, q = (int)threadIdx.x % Q;
+  const int per = (nblocks + Q - 1) / Q, b0 = min(nblocks, q * per), b1 = min(nblocks, b0 + per);
+  int acc = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int c = counts[bin * nblocks + b];
+    counts[bin * nblocks + b] = acc;
+    acc += c;
+  }
+  part[bin][q] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int l = kPxBins - 1; l >= 0; --l) {       // longest chains first
+      int tot = 0;
+      for (int k = 0; k < Q; ++k) { const int c = part[l][k]; part[l][k] = tot; tot += c; }
+      bin_start[l] = a;
+      a += tot;
+    }
+    bin_start[kPxBins] = a;                        // all pixels
+    // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
+    // with longer chains than its own longest.  (pixels of >= t rays = bin_start[t - 1] for t >= 1: the bins above t - 1)
+    auto at_least = [&](int t) { return t <= 0 ? a : (t > kPxBins - 1 ? 0 : bin_start[t - 1]); };
+    int t0 = max(thr0, 1);
+    while (t0 < kPxBins && at_least(t0) > solo_cap) ++t0;   // the one-pixel class: at most solo_cap pixels
+    const int t1 = min(thr1, t0), t2 = min(thr2, t1), t3 = min(thr3, t2);
+    int pos[kPxClasses + 1] = {0, at_least(t0), at_least(t1), at_least(t2), at_least(t3), a};
+    px_make_header(pos, hdr);
+  }
+  __syncthreads();
+  for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
+}
+__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
+                                                            unsigned *list) {
+  __shared__ int cursor[kPxBins];
+  if (threadIdx.x < kPxBins) cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
+  __syncthreads();
+  px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
+    const int pos = atomicAdd(&cursor[px_bin(rays)], 1);
+    list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
+  });
+}
+
+hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const int thr[kPxClasses - 1], int solo_cap, unsigned *list, int *hdr,
+                           int *scratch, hipStream_t stream) {
+  const int ntiles = g.tiles_x * g.tiles_y;
+  if (ntiles <= 0) return hipSuccess;
+  int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
+  while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
+  const int nblocks = (ntiles + tpb - 1) / tpb;
+  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch);
+  hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxThreads), 0, stream, scratch, nblocks, thr[0], thr[1], thr[2], thr[3], solo_cap, hdr);
+  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, list);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // Framebuffer assembly: scatter one part's packed rows into the full image.
 // ---------------------------------------------------------------------------------
 __global__ void place_part_kernel(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile,
@@ -1417,10 +1605,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0, bool ORD = false>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL, ORD>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1432,6 +1620,11 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
+  // (ORD: pixel tickets; workgroups of 16 waves only)
+  if (p.px_hdr != nullptr) {
+    if (waves_per_wg != 16 || p.nframes != 1) return hipErrorInvalidValue;
+    return all_lds ? launch_pooled_t<1024, true, false, true, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, false, true, 0, true>(p, grid, stream);
+  }
   // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
   if (p.cold && waves_per_wg == 16)
     return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, 1>(p, grid, stream) : launch_pooled_t<1024, true, false, false, 1>(p, grid, stream))
@@ -1468,6 +1661,13 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 2>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 1>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 1>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 0, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)px_count_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)px_scan_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)px_place_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_place_kernel);

@@ -58,13 +58,48 @@ __host__ __device__ inline unsigned shard_tickets(unsigned npos, unsigned n_spli
   return (n_split << ds) + (n_deep - n_split) + ((npos - n_deep + (1u << tpt) - 1u) >> tpt);
 }
 // ticket t < shard_tickets(...) -> the pixels it covers, as [q_next, q_end) in units of (position * 64 + pixel in tile)
-struct TicketSpan { unsigned q_next, q_end; };
+struct TicketSpan { unsigned q_next, q_end; unsigned cls; };   // cls: pixel tickets only (kPxClasses - 1 for tile tickets)
+
+// ---- pixel tickets (round 5): an ORDERED single frame's queue runs over a list of the view's PIXELS sorted by the length of
+// their bounce chains (recorded by the view's first frame, px_order kernels in render_kernels.hip), longest first, cut into
+// kPxClasses segments by chain length.  A ticket of class k covers 1 << kPxLog2[k] consecutive pixels of the list: the longest
+// chains go out one pixel per ticket (traced by the solo loop), the next ones 8 / 16 / 32 per ticket to waves that do not refill
+// while they trace them (a wave's bounce cadence grows with the rays it carries: ~8 us per bounce with 16 rays, ~17 with 40), the
+// bulk 64 per ticket.  The table's header (kPxHdrInts ints, device memory, written by px_scan_kernel):
+//   [0 .. 5] first list position of class k (k = 5: the number of pixels)   [8 .. 13] first ticket of class k (k = 5: all tickets)
+constexpr int kPxClasses = 5;
+constexpr int kPxHdrInts = 16;
+__host__ __device__ inline int px_log2(int cls) { return cls == 0 ? 0 : cls + 2; }   // 1, 8, 16, 32, 64 pixels
+__host__ __device__ inline TicketSpan px_ticket_span(unsigned t, const int *hdr) {
+  int k = 0;
+  while (k + 1 < kPxClasses && t >= (unsigned)hdr[8 + k + 1]) ++k;
+  TicketSpan sp;
+  sp.cls = (unsigned)k;
+  sp.q_next = (unsigned)hdr[k] + ((t - (unsigned)hdr[8 + k]) << px_log2(k));
+  const unsigned end = sp.q_next + (1u << px_log2(k)), seg_end = (unsigned)hdr[k + 1];
+  sp.q_end = end < seg_end ? end : seg_end;
+  return sp;
+}
+// the header for a list whose classes start at the positions pos[0 .. kPxClasses] (pos[0] = 0, non-decreasing)
+__host__ __device__ inline void px_make_header(const int *pos, int *hdr) {
+  int tick = 0;
+  for (int k = 0; k < kPxClasses; ++k) {
+    hdr[k] = pos[k];
+    hdr[8 + k] = tick;
+    tick += (pos[k + 1] - pos[k] + (1 << px_log2(k)) - 1) >> px_log2(k);
+  }
+  hdr[kPxClasses] = pos[kPxClasses];
+  hdr[8 + kPxClasses] = tick;
+  hdr[6] = hdr[7] = hdr[14] = hdr[15] = 0;
+}
 __host__ __device__ inline TicketSpan ticket_span(unsigned t, unsigned seg, unsigned npos, unsigned n_split, unsigned n_deep, int ds, int tpt) {
   TicketSpan sp;
+  sp.cls = kPxClasses - 1;
   if (t < (n_split << ds)) {
     const unsigned piece = 64u >> ds;
     sp.q_next = (seg + (t >> ds)) * 64u + (t & ((1u << ds) - 1u)) * piece;
     sp.q_end = sp.q_next + piece;
+    sp.cls = kPxClasses - 1;
     return sp;
   }
   t -= n_split << ds;
@@ -90,6 +125,7 @@ struct QueueConst {
   int ntiles;                // all shards' tiles: the class tables sit at order[ntiles + kOrderTableDw * shard]
   const int *order;          // nullptr: no tables
   int deep_class;            // 0: no deep tiles
+  const int *px;             // pixel tickets: the list's header (px_ticket_span); nullptr: tile tickets.  (One queue: interleave, or a single counter.)
   unsigned home_waves;       // waves whose home is one shard (total waves >> ns_log2)
   unsigned q_static;         // tickets [0, q_static) of every shard are the home waves' first tickets: never drawn from the counter
 };
@@ -123,7 +159,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
     const unsigned npos = (unsigned)s.ntiles * (unsigned)c.nframes;
     const int ndeep = queue_ndeep(c, geo);               // (<= the shard's tiles: a position of its class table)
     const unsigned n_split = queue_nsplit(c, ndeep);
-    unsigned tickets = shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
+    unsigned tickets = c.px != nullptr ? (unsigned)c.px[8 + kPxClasses] : shard_tickets(npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
     // interleaved: this counter's tickets are the queue's tickets sh, sh + n, sh + 2 n, ... (n counters)
     if (c.interleave) tickets = (tickets + (1u << c.ns_log2) - 1u - (unsigned)sh) >> c.ns_log2;
     unsigned t = 0;
@@ -138,7 +174,7 @@ __host__ __device__ inline bool queue_draw(unsigned &state, const QueueConst &c,
     }
     if (got) {
       if (c.interleave) t = (t << c.ns_log2) + (unsigned)sh;
-      *sp = ticket_span(t, (unsigned)s.seg, npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
+      *sp = c.px != nullptr ? px_ticket_span(t, c.px) : ticket_span(t, (unsigned)s.seg, npos, n_split, (unsigned)ndeep, c.ds, c.tpt);
       return true;
     }
     state |= 0x100u << sh;
@@ -202,6 +238,10 @@ struct KParams {
   int deep_split;        // log2 of the pieces a deep tile is handed out in (2: four tickets of two rows each; 0: whole)
   int deep_cap_log2;     // ... to at most one in 2^this of the launch's waves (5)
   int *cost;             // [nchunks] longest bounce chain seen per tile (nullptr: not recorded)
+  unsigned char *cost_px;   // [h * w] with `cost`, single frames: rays traced per PIXEL (depth + 1, saturating), indexed like `out` (nullptr: not recorded)
+  const int *px_hdr;     // pixel tickets (the ORD instantiation; nullptr: tile tickets): header of the view's pixel list (kPxHdrInts) ...
+  const unsigned *px_list;   // ... and the list itself: (local row << 16) | column, longest bounce chains first
+  int px_hold;           // bit k: a wave that draws a ticket of class k does not refill until it is finished
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
 };
@@ -234,6 +274,16 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &out, cha
 constexpr int kOrderBlocksMax = 64;                                   // workgroups per shard of the tile-order sort
 constexpr int kOrderScratchInts = kMaxShards * 64 * kOrderBlocksMax;   // its scratch: [shard][bin][workgroup] counts
 hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int nshards, int *scratch, hipStream_t stream);
+// The view's pixel list from the per-pixel record of its first frame (px_count / px_scan / px_place kernels): pixels by
+// descending chain length, header per px_make_header with the classes cut at chains of >= thr[k] rays (thr[0] >= thr[1] >= ...;
+// the one-pixel class also capped at `solo_cap` pixels).  `scratch`: px_scratch_ints(ntiles) ints.
+struct PxGeom {
+  int w, rows_local, rpt_log2, out_skip, tiles_x, tiles_y;
+};
+constexpr int kPxBlocksMax = 2048;
+constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax; }
+hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const int thr[kPxClasses - 1], int solo_cap, unsigned *list, int *hdr,
+                           int *scratch, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

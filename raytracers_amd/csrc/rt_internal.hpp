@@ -51,10 +51,15 @@ struct rt_context {
   int xcd_queues = -1;      // pooled family: the tile queue's ticket counters (rt_device.hpp). -1 (auto) = 2: eight counters, one per XCD, taking turns over ONE queue, for every frame and batch; 1: a strip of tile columns per counter (single frames only); 0: one counter
   int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers. -1 (auto): 0 for a single frame; a batch 2, 1 or 0 by the tiles a wave gets (>= 48, >= 24, fewer)
   int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
+  int pixel_order = 1;      // pooled family: an ordered single frame draws its tickets from the view's PIXEL list (rt_device.hpp: pixel tickets; the ORD instantiation). 0 = tile tickets only; 1 = where measured faster (api.cpp); 2 = whenever the view has a list (testing)
+  int px_thr[4] = {24, 24, 14, 9};   // ... the list's classes: chains of >= px_thr[0] rays go out one pixel per ticket (solo loop), >= [1] 8 per ticket, >= [2] 16, >= [3] 32, the rest 64
+  int px_hold = 0xf;        // ... bit k: a wave holding a ticket of class k does not refill (classes 0 .. 3: 1, 8, 16, 32 pixels)
+  int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
   // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
   unsigned *queue_dev = nullptr;
   int *order_scratch = nullptr;   // the tile-order sort's chunk counts (rtk::kOrderScratchInts), allocated with the first record
+  int *px_scratch = nullptr;      // the pixel-list sort's counts (rtk::px_scratch_ints()), likewise
   unsigned long long *stats_dev = nullptr;
   // per-(w, h) tables of the primary-ray parameters u = i / w and v = (h - row) / h
   struct UvTable {
@@ -105,6 +110,11 @@ struct TileOrder {
   int *cost = nullptr;    // [ntiles] record written by the render kernel
   int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
+  // pixel tickets (single frames of the view; rt_device.hpp): the per-pixel record of the first frame, the list sorted from it
+  unsigned char *cost_px = nullptr;   // [cost_px_bytes] rays traced per pixel, indexed like the framebuffer (h * w: a part rendered in place stores at its rows' places)
+  unsigned *px_list = nullptr;        // [px_elems] the part's pixels, longest chains first; then the header (rtk::kPxHdrInts)
+  size_t cost_px_bytes = 0, px_elems = 0;
+  bool px_valid = false;
   uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
   bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
   int classes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -55,6 +55,7 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
   qc.ds = c.ds; qc.tpt = c.tpt; qc.cap_log2 = c.cap_log2; qc.ntiles = ntiles; qc.interleave = c.interleave;
   const bool deep_on = c.nframes == 1 && c.deep_class > 0;
   qc.order = deep_on ? order.data() : nullptr; qc.deep_class = c.deep_class;
+  qc.px = nullptr;
   qc.home_waves = static_cast<unsigned>(c.waves >> c.ns_log2);
   qc.q_static = c.static_first ? qc.home_waves : 0u;
 
@@ -123,6 +124,70 @@ static int run(const Cfg &c, std::mt19937 &rng, bool verbose) {
   return 0;
 }
 
+// Pixel tickets (rt_device.hpp: px_make_header / px_ticket_span through queue_draw): a random list of `npix` pixels cut into the
+// five classes at random positions; every list position is handed out exactly once, a ticket of class k covers at most
+// 1 << px_log2(k) positions of class k's segment, and every ticket of a class but its last one is full.
+static int run_px(std::mt19937 &rng, bool verbose) {
+  const int npix = 1 + static_cast<int>(rng() % 20000);
+  int pos[kPxClasses + 1];
+  pos[0] = 0;
+  pos[kPxClasses] = npix;
+  for (int k = 1; k < kPxClasses; ++k) pos[k] = static_cast<int>(rng() % static_cast<unsigned>(npix + 1)) / ((rng() & 1) ? 1 : 16);
+  for (int k = 1; k < kPxClasses; ++k) if (pos[k] < pos[k - 1]) pos[k] = pos[k - 1];
+  int hdr[kPxHdrInts];
+  px_make_header(pos, hdr);
+  QueueConst qc{};
+  qc.ns_log2 = (rng() & 1) ? 3 : 0;
+  qc.interleave = qc.ns_log2 == 3;
+  qc.tiles_x = 1 + static_cast<int>(rng() % 40); qc.tiles_y = 1 + static_cast<int>(rng() % 40); qc.nframes = 1;   // (unused by pixel tickets)
+  qc.ds = static_cast<int>(rng() % 7); qc.tpt = static_cast<int>(rng() % 3); qc.cap_log2 = 5; qc.ntiles = qc.tiles_x * qc.tiles_y;
+  qc.order = nullptr; qc.deep_class = 0; qc.px = hdr;
+  const int waves = 32 * (1 + static_cast<int>(rng() % 40)), ns = 1 << qc.ns_log2;
+  const int static_first = static_cast<int>(rng() & 1);
+  qc.home_waves = static_cast<unsigned>(waves >> qc.ns_log2);
+  qc.q_static = static_first ? qc.home_waves : 0u;
+  std::vector<unsigned> counter(static_cast<size_t>(ns), 0u);
+  std::vector<unsigned char> cover(static_cast<size_t>(npix), 0);
+  const int wpw = 4, grid = waves / wpw;
+  struct Wave { unsigned state, rank; };
+  std::vector<Wave> wv(static_cast<size_t>(waves));
+  std::vector<int> alive(static_cast<size_t>(waves));
+  for (int w = 0; w < waves; ++w) {
+    const int b = w / wpw, wi = w % wpw;
+    wv[static_cast<size_t>(w)].state = queue_state_init(b & (ns - 1), static_first != 0);
+    wv[static_cast<size_t>(w)].rank = static_cast<unsigned>(wi) * static_cast<unsigned>(grid >> qc.ns_log2) + static_cast<unsigned>(b >> qc.ns_log2);
+    alive[static_cast<size_t>(w)] = w;
+  }
+  unsigned long long taken = 0;
+  while (!alive.empty()) {
+    const size_t pick = rng() % alive.size();
+    Wave &W = wv[static_cast<size_t>(alive[pick])];
+    TicketSpan sp;
+    if (!queue_draw(W.state, qc, W.rank, [&](int shard) { return counter[static_cast<size_t>(shard)]++; }, &sp)) {
+      alive[pick] = alive.back();
+      alive.pop_back();
+      continue;
+    }
+    taken++;
+    const int k = static_cast<int>(sp.cls);
+    if (k < 0 || k >= kPxClasses || sp.q_end <= sp.q_next || sp.q_next < static_cast<unsigned>(pos[k]) || sp.q_end > static_cast<unsigned>(pos[k + 1]) ||
+        sp.q_end - sp.q_next > (1u << px_log2(k)) || (sp.q_end - sp.q_next < (1u << px_log2(k)) && sp.q_end != static_cast<unsigned>(pos[k + 1]))) {
+      std::printf("pixel ticket: bad span [%u, %u) of class %d (segment [%d, %d))\n", sp.q_next, sp.q_end, k, pos[k], pos[k + 1]);
+      return 1;
+    }
+    for (unsigned i = sp.q_next; i < sp.q_end; ++i) {
+      if (cover[i]) { std::printf("pixel ticket: list position %u handed out twice\n", i); return 1; }
+      cover[i] = 1;
+    }
+  }
+  for (int i = 0; i < npix; ++i)
+    if (!cover[static_cast<size_t>(i)]) { std::printf("pixel ticket: list position %d never handed out\n", i); return 1; }
+  if (taken != static_cast<unsigned long long>(hdr[8 + kPxClasses])) { std::printf("pixel tickets: %llu taken, header says %d\n", taken, hdr[8 + kPxClasses]); return 1; }
+  if (verbose) std::printf("ok: pixel tickets, %d pixels, classes at %d %d %d %d, %d counter(s), %d waves, static %d: %llu tickets\n", npix, pos[1], pos[2], pos[3],
+                           pos[4], ns, waves, static_first, taken);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int cases = argc > 1 ? std::atoi(argv[1]) : 2000;
   const unsigned seed = argc > 2 ? static_cast<unsigned>(std::atoi(argv[2])) : 1u;
@@ -154,6 +219,11 @@ int main(int argc, char **argv) {
       return 1;
     }
   }
+  for (int i = 0; i < cases; ++i)
+    if (run_px(rng, i < 3)) {
+      std::printf("FAILED pixel-ticket case %d (seed %u)\n", i, seed);
+      return 1;
+    }
   std::printf("queue_check: %d random cases + %zu fixed ones passed\n", cases, sizeof(fixed) / sizeof(fixed[0]));
   return 0;
 }
