@@ -321,6 +321,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=10, help="independent steps enqueued concurrently (streams); capped by --steps")
     ap.add_argument("--event-every", type=int, default=1,
                     help="bracket the launches of every n-th timed step with HIP events (kernel duration samples)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed K-step bracket is run this many times (warm-up passes, poison, bracket, verification each time); "
+                         "steps / ms_per_step / value describe the MEDIAN bracket, brackets_ms lists them all (1: one bracket, as before round 5)")
     ap.add_argument("--no-serial-extra", action="store_true", help="skip the extra serial (one frame at a time) region")
     ap.add_argument("--idle-before-ms", type=float, default=0.0,
                     help="experiment: idle the GPU this long between the warm-up steps and the timed bracket (DESIGN.md 6, first-process effect)")
@@ -563,6 +566,18 @@ def main():
         time.sleep(args.idle_before_ms * 1e-3)
     elapsed, kern_ms = timed(args.steps, S)
     n_verified = verify(lanes, "timed region,")
+    # --repeats R: the identical bracket again, R - 1 times -- each behind its own untimed warm-up passes (the verification
+    # before them reads the images back, i.e. lets the GPU idle: the passes bring the clock back) and its own
+    # poison, each verified.  The line reports the median bracket; a single 7 ms bracket moved by +-1.3 % from box to box.
+    brackets = [(elapsed, kern_ms)]
+    for _ in range(max(1, args.repeats) - 1):
+        for k in range(2 * S if (batch and args.warmup > 0) else args.warmup):
+            step(k)
+        poison(lanes)
+        brackets.append(timed(args.steps, S))
+        n_verified += verify(lanes, "timed region (repeat),")
+    brackets_ms = [b[0] * 1e3 for b in brackets]
+    elapsed, kern_ms = sorted(brackets, key=lambda b: b[0])[(len(brackets) - 1) // 2]
     serial = None
     if serial_lane is not None:
         for k in range(4):              # render + sync, as the reference's harness does: the view's order after frame 1, its deep-tile
@@ -713,6 +728,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (the reference's procedural scenes)",
             "verified": True, "verified_images": n_verified,
+            **({"repeats": len(brackets), "brackets_ms": brackets_ms,
+                "value_min": rays_step * args.steps / (max(brackets_ms) * 1e-3) / 1e6, "value_max": rays_step * args.steps / (min(brackets_ms) * 1e-3) / 1e6,
+                "repeats_note": f"{len(brackets)} identical brackets of {args.steps} steps, each behind its own warm-up passes and poison fill, each verified; "
+                                "value / ms_per_step are the median bracket's"} if len(brackets) > 1 else {}),
             "rccl_ranks": (dist.get_world_size() if (use_pg and not share_gpu) else 0),
             "gather_mode": ("none (one GPU, whole frames)" if not use_pg else
                             "direct-store: every rank's kernel stores its pixels into rank 0's image (IPC mapping) while it renders; "

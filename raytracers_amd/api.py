@@ -136,7 +136,8 @@ class DeviceBuffer:
         assert n * 4 <= self.nbytes
         iface = {"shape": tuple(int(x) for x in shape), "typestr": "<i4", "data": (int(self.ptr), False), "version": 2}
         holder = type("_CudaArray", (), {"__cuda_array_interface__": iface})()
-        return torch.as_tensor(holder, device="cuda")
+        # (the device that owns the buffer, not torch's current one: a context on another GPU would get a mislabelled tensor)
+        return torch.as_tensor(holder, device=torch.device("cuda", self.ctx.device_info()["device"]))
 
     def to_host(self, shape):
         out = np.empty(shape, dtype=np.int32)

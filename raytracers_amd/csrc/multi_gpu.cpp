@@ -39,6 +39,7 @@ struct rt_group {
   bool peer_ok = true;              // every device can store into the first device's memory (peer access enabled, or the same device)
   hipEvent_t ev_begin = nullptr;    // direct stores: the parent stream's position when the frame was asked for (the image's previous readers)
   bool last_direct = false;         // what carried the last frame (rt_context_gather_mode)
+  bool rendered = false;            // a frame has been rendered (before that the getter reports what auto WOULD pick)
   // gather buffers, grown on demand
   int64_t buf_elems = 0;            // capacity of one part in int32
   std::vector<int32_t *> part;      // part[i] on device i (kid 0 renders into the stacked buffer unless gather == 2)
@@ -171,7 +172,8 @@ extern "C" int rt_context_num_devices(const rt_context *ctx) {
 extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
   if (!ctx || !ctx->group || ctx->group->kids.size() < 2) return ctx && ctx->group && ctx->group->gather == 2 ? "rccl" : "none";
   rt_group *g = ctx->group;
-  if (g->gather == 3 || (g->gather == 0 && g->peer_ok)) return "direct-store";
+  // (auto: what the last frame was carried by -- an image the other devices cannot be shown to reach goes through the gather)
+  if (g->gather == 3 || (g->gather == 0 && g->peer_ok && (g->last_direct || !g->rendered))) return "direct-store";
   if (g->gather == 1 || g->rccl_failed || !g->distinct) return "peer-copy";
   if (!g->rccl_tried) return "rccl (loaded at the first frame; peer copies if that fails)";   // (a getter creates no communicators)
   return g->comms.empty() ? "peer-copy" : "rccl";
@@ -285,7 +287,18 @@ int rti::group_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t
   if (nframes < 1 || (nframes > 1 && (frame_stride < h * w || frame_stride * nframes >= (int64_t(1) << 31))))
     return fail(ctx, "bad batch: nframes >= 1, frame_stride >= h * w, nframes * frame_stride < 2^31");
   constexpr int32_t kRows = 8;
-  if (g->gather == 3 || (g->gather == 0 && g->peer_ok)) {
+  // Auto mode takes the direct path only for an image the other devices can certainly reach: a device allocation on the first
+  // device, which hipDeviceEnablePeerAccess covers (memory from a virtual-memory mapping or another device's pool is not, and
+  // an unreadable pointer says nothing) -- any other image goes through the gather, which only the first device touches.
+  bool direct = g->gather == 3;
+  if (g->gather == 0 && g->peer_ok) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, out_dev) == hipSuccess) direct = at.type == hipMemoryTypeDevice && at.device == g->devices[0];
+    else (void)hipGetLastError();
+  }
+  g->last_direct = direct;
+  g->rendered = true;
+  if (direct) {
     // ---- direct stores: every device writes its rows where the image has them; nothing is gathered or assembled ----
     // (the image's previous readers sit on the parent's stream: the devices start behind them)
     RT_HIP(ctx, hipSetDevice(ctx->device));

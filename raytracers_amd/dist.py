@@ -158,16 +158,24 @@ class ShardedStep:
         sizes = [self.nbatch * h * w for _, h, w in self.frames]
         self.img_offs = [int(o) for o in np.concatenate([[0], np.cumsum(sizes)])]
         handle, ok, err = None, 1, ""
-        try:
-            if self.rank == self.dst:
+        # Every rank makes the same two collectives whatever fails locally: rank dst's allocation / export failing must not
+        # keep it out of the broadcast the other ranks are already waiting in (it then broadcasts None, which they read as
+        # "no buffer"), and every rank reaches the all-gather of the outcomes below.
+        if self.rank == self.dst:
+            try:
                 self._ipc_buf = r0.ctx.alloc_i32(self.img_offs[-1])
                 handle = api.ipc_export(r0.ctx, self._ipc_buf.ptr)
-            box = [handle]
-            dist.broadcast_object_list(box, src=self.dst, group=self.group)
-            if self.rank != self.dst:
+            except Exception as e:   # noqa: BLE001 -- whatever went wrong, every rank must learn of it
+                handle, ok, err = None, 0, f"rank {self.rank}: {e}"
+        box = [handle]
+        dist.broadcast_object_list(box, src=self.dst, group=self.group)
+        if self.rank != self.dst:
+            try:
+                if box[0] is None:
+                    raise RuntimeError(f"rank {self.dst} exported no buffer")
                 self._ipc_base = api.ipc_import(r0.ctx, box[0])
-        except Exception as e:   # noqa: BLE001 -- whatever went wrong, every rank must learn of it
-            ok, err = 0, f"rank {self.rank}: {e}"
+            except Exception as e:   # noqa: BLE001
+                ok, err = 0, f"rank {self.rank}: {e}"
         oks = [None] * self.world
         dist.all_gather_object(oks, (ok, err), group=self.group)
         if not all(o for o, _ in oks):
@@ -205,6 +213,7 @@ class ShardedStep:
         if self.exchange_mode != "direct":
             return
         self.images = None
+        self.send = None            # (rank dst: a view of the buffer that is about to be freed)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if self.rank != self.dst:

@@ -1233,11 +1233,18 @@ def test_bench_line_contract(tmp_path, force_gather):
     if force_gather:
         env["RT_FORCE_GATHER"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                          "--no-cpu-baseline"] + (["--repeats", "1"] if force_gather else []), capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[:500]
     d = json.loads(lines[0])
+    if force_gather:      # --repeats 1: one bracket, the line of the rounds before --repeats existed
+        assert "repeats" not in d and "brackets_ms" not in d
+    else:                 # the default: five identical brackets, the line describes the median one
+        assert d["repeats"] == 5 and len(d["brackets_ms"]) == 5
+        assert abs(d["ms_per_step"] * d["steps"] - sorted(d["brackets_ms"])[2]) < 1e-9
+        assert d["value_min"] <= d["value"] <= d["value_max"]
+        assert d["verified_images"] >= 5 * 2 * 6 + 2
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
