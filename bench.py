@@ -142,6 +142,31 @@ def kernel_source_hash(legacy=False):
     return m.hexdigest()
 
 
+def load_scale_prediction(world):
+    """what tools/scale_prediction.py predicted for this world size from one-GPU measurements (profiles/r*/scale_prediction.json,
+    the latest round's): printed next to the measured irreg 4000x4000 figures so that one multi-GPU run tests the model's two
+    assumed constants (25 us per ordering signal, half link rate for 4-byte stores)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "scale_prediction.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    row = (d.get("worlds") or {}).get(str(world)) if isinstance(d, dict) else None
+    if not isinstance(row, dict):
+        out["note"] = f"no row for world size {world}"
+        return out
+    for key in ("irreg_4000_one_frame", "irreg_4000_one_frame_direct", "irreg_4000_batch_of_6", "irreg_4000_batch_of_6_direct",
+                "headline_1000", "headline_1000_direct"):
+        if key in row:
+            out[key] = {k: row[key][k] for k in ("us_per_frame", "us_per_step", "speedup_vs_1") if k in row[key]}
+    return out
+
+
 def effective_cpus():
     """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
     (the GPU boxes show 256 hardware threads but grant 16 CPUs' worth of time; 256 OpenMP threads
@@ -423,11 +448,12 @@ def main():
 
     class Lane:
         """the renderers of one launch in flight + the step (render all, exchange, assemble)"""
-        def __init__(self, o, fr=frames, nbatch=1):
+        def __init__(self, o, fr=frames, nbatch=1, exch=None):
             self.fr = fr
+            exch = exch or exchange
             self.prs = [HipPartRenderer(scene, h, w, device, variant=args.variant, options=o) for scene, h, w in fr]
-            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch, exchange=exchange)
-            if exchange == "direct" and self.step.exchange_mode != "direct" and rank == 0:
+            self.step = ShardedStep([(pr, h, w) for pr, (_, h, w) in zip(self.prs, fr)], device, nbatch=nbatch, exchange=exch)
+            if exch == "direct" and self.step.exchange_mode != "direct" and rank == 0:
                 log(f"bench.py: {self.step.exchange_note}")
 
     def build_lanes():
@@ -655,9 +681,13 @@ def main():
 
     # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
     scale_extra = None
-    if world > 1 and not args.no_scale_extra and args.workload == "rgbbox+irreg-1000":
+
+    def irreg_4000_record(exch):
+        """irreg 4000x4000 across the ranks through one exchange: one frame at a time, then the same frames as one batch"""
+        nonlocal n_verified
         fr4 = [("irreg", 4000, 4000)]
-        big_lane = Lane(opts, fr4)
+        big_lane = Lane(opts, fr4, exch=exch)
+        mode = big_lane.step.exchange_mode
         for _ in range(3):
             big_lane.step.render()
             torch.cuda.synchronize()      # (render + sync: the view's policy arrives asynchronously, see the serial lane)
@@ -677,11 +707,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tmin = t.clone()
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        n_verified += verify([big_lane], "irreg 4000x4000,")
+        n_verified += verify([big_lane], f"irreg 4000x4000 ({mode}),")
         # ... and the same frames as ONE batch launch per rank (one frame at a time cannot end before its longest bounce chain)
         big_lane.step.close()             # (direct exchange: the other ranks unmap rank 0's images before it frees them; collective)
         del big_lane
-        bb = Lane(opts, fr4, nbatch=n4)
+        bb = Lane(opts, fr4, nbatch=n4, exch=exch)
         for _ in range(2):
             bb.step.render()
         torch.cuda.synchronize()
@@ -692,20 +722,34 @@ def main():
         fence()
         tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-        n_verified += verify([bb], "irreg 4000x4000 batch,")
+        n_verified += verify([bb], f"irreg 4000x4000 batch ({mode}),")
         bb.step.close()
         del bb
+        if rank != 0:
+            return None
+        r4 = FRAME_WORK[("irreg", 4000, 4000)][0]
+        ms = float(tmax[0].item()) / n4 * 1e3
+        return {"workload": "irreg 4000x4000, one frame at a time (render + exchange + sync per frame)", "exchange": mode,
+                "ms_per_frame": ms, "Mray_s": r4 / ms / 1e3,
+                "render_us_per_rank": {"slowest": float(tmax[1].item()) * 1e3, "fastest": float(tmin[1].item()) * 1e3},
+                "gather_and_assemble_us_rank0": float(np.mean([a.elapsed_time(b) for a, b in evg])) * 1e3,
+                "batch": {"frames_per_launch": n4, "ms_per_frame": float(tb[0].item()) / n4 * 1e3,
+                          "Mray_s": r4 * n4 / float(tb[0].item()) / 1e6,
+                          "note": "the same frames in one rt_render_batch launch per rank + one exchange"},
+                "frames": n4, "verified": True}
+
+    if world > 1 and not args.no_scale_extra and args.workload == "rgbbox+irreg-1000":
+        # BOTH exchanges in one run (the driver's multi-GPU box is the only place they can be compared): the one the headline ran
+        # on first -- it is the `irreg_4000` record -- then the other one; each verified against the oracle's checksum
+        recs = {}
+        for exch in ([exchange] + [e for e in ("direct", "gather") if e != exchange and (e == "gather" or args.exchange != "gather")]):
+            rec = irreg_4000_record(exch)
+            if rank == 0 and rec["exchange"] not in recs:
+                recs[rec["exchange"]] = rec
         if rank == 0:
-            r4 = FRAME_WORK[("irreg", 4000, 4000)][0]
-            ms = float(tmax[0].item()) / n4 * 1e3
-            scale_extra = {"workload": "irreg 4000x4000, one frame at a time (render + gather + sync per frame)",
-                           "ms_per_frame": ms, "Mray_s": r4 / ms / 1e3,
-                           "render_us_per_rank": {"slowest": float(tmax[1].item()) * 1e3, "fastest": float(tmin[1].item()) * 1e3},
-                           "gather_and_assemble_us_rank0": float(np.mean([a.elapsed_time(b) for a, b in evg])) * 1e3,
-                           "batch": {"frames_per_launch": n4, "ms_per_frame": float(tb[0].item()) / n4 * 1e3,
-                                     "Mray_s": r4 * n4 / float(tb[0].item()) / 1e6,
-                                     "note": "the same frames in one rt_render_batch launch per rank + one gather"},
-                           "frames": n4, "verified": True}
+            scale_extra = dict(next(iter(recs.values())))
+            scale_extra["by_exchange"] = {m: {k: v for k, v in r.items() if k not in ("workload", "frames", "verified")} for m, r in recs.items()}
+            scale_extra["predicted"] = load_scale_prediction(world)
 
     if rank == 0:
         rays_step = sum(work[(s, h, w)][0] for s, h, w in frames)

@@ -32,12 +32,16 @@ typedef struct rt_prepared rt_prepared;  /* `prepared_scene` (ray.fut:239): devi
 
 /* Kernel families (rt_context_set_variant).  All produce bit-identical pixels. */
 enum {
-  RT_VARIANT_AUTO = 0,        /* best known configuration for the scene size */
+  RT_VARIANT_AUTO = 0,        /* the pooled family; the pixel family for scenes beyond its limits: 2^22 spheres or more
+                                 (a pooled work item is one dword, (node or leaf << 8) | ray slot) or a tree deeper than
+                                 64 levels (the per-wave box stack no longer fits LDS) -- ~2 Gray/s instead of 6-16 */
   RT_VARIANT_PIXEL = 1,       /* one thread per pixel, BVH in HBM/L2, no LDS staging (BASELINE configs[1]) */
-  RT_VARIANT_PERSISTENT = 2,  /* persistent waves: work queue + in-place lane refill + phase voting,
-                                 top BVH levels staged in LDS (BASELINE configs[2]) */
-  RT_VARIANT_POOLED = 3       /* persistent waves whose lanes share LDS work lists of (ray slot, node)
-                                 items: any lane tests any ray's node; ballot/mbcnt compaction */
+  RT_VARIANT_PERSISTENT = 2,  /* CROSS-CHECK family, selected by nothing: one ray per lane, work queue + in-place lane
+                                 refill + phase voting.  A structurally different implementation of the same fold that
+                                 the parity suite renders every case through; 5-15x slower than the pooled family */
+  RT_VARIANT_POOLED = 3       /* persistent waves whose lanes share LDS work lists of (ray slot, node) items: any lane
+                                 tests any ray's node; ballot/mbcnt compaction; work queue of tiles, or of the view's
+                                 pixels sorted by bounce-chain length (BASELINE configs[2..4]) */
 };
 
 /* ---- context ------------------------------------------------------------------ */
@@ -60,6 +64,7 @@ int rt_device_count(void);   /* usable HIP devices (0: none -- there is no CPU p
 int rt_context_create_multi(rt_context **out, const int *devices, int ndev);
 int rt_context_num_devices(const rt_context *ctx);          /* 1 for an ordinary context */
 const char *rt_context_gather_mode(rt_context *ctx);        /* "none", "direct-store", "rccl" or "peer-copy" (static strings) */
+int rt_context_rccl_ranks(rt_context *ctx);                 /* ranks of the RCCL communicator behind the gather (0: RCCL is not what carries it) */
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
 int rt_context_sync(rt_context *ctx);

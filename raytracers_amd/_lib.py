@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, LIB_NAME)
 
 # every symbol include/rt_mi355x.h declares
 RT_SYMBOLS = [
-    "rt_context_create", "rt_device_count", "rt_context_create_multi", "rt_context_num_devices", "rt_context_gather_mode",
+    "rt_context_create", "rt_device_count", "rt_context_create_multi", "rt_context_num_devices", "rt_context_gather_mode", "rt_context_rccl_ranks",
     "rt_context_destroy", "rt_last_error", "rt_context_sync", "rt_context_set_variant",
     "rt_context_set_option", "rt_context_device_info",
     "rt_scene_rgbbox", "rt_scene_irreg", "rt_scene_floor", "rt_scene_from_spheres", "rt_scene_num_spheres",
@@ -56,6 +56,7 @@ def _load():
         "rt_context_create_multi": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
         "rt_context_num_devices": (C.c_int, [vp]),
         "rt_context_gather_mode": (C.c_char_p, [vp]),
+        "rt_context_rccl_ranks": (C.c_int, [vp]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, [vp]),
         "rt_context_sync": (C.c_int, [vp]),

@@ -71,6 +71,11 @@ class Context:
     def gather_mode(self):
         return lib.rt_context_gather_mode(self._h).decode()
 
+    @property
+    def rccl_ranks(self):
+        """ranks of the RCCL communicator behind a multi-device context's gather (0: RCCL is not what carries it)"""
+        return int(lib.rt_context_rccl_ranks(self._h))
+
     def set_variant(self, v):
         self._check(lib.rt_context_set_variant(self._h, int(v)))
 

@@ -556,9 +556,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         // ... and the view's pixel list from the per-pixel record
         if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
         const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, p.out_skip, p.tiles_x, p.tiles_y};
-        const int solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
-        RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, ctx->px_thr, solo_cap, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems),
-                                         ctx->px_scratch, ctx->stream));
+        rtk::PxPolicy pol{};
+        for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
+        // the model's bounce cadences (0.1 us; measured, profiles/r05/exp): a scene that lives in LDS, one that is read from L2
+        const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
+        static const int g_lds[5] = {25, 45, 65, 100, 160}, g_l2[5] = {45, 70, 100, 190, 330};
+        for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
+        pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 300;
+        pol.nwaves = pl.grid_full * pl.waves;
+        pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+        RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
+                                         ctx->stream));
         to->px_valid = true;
       }
     }
@@ -761,7 +769,11 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
   } else if (k == "pixel_order") {
     ctx->pixel_order = std::max(0, std::min(2, v));
   } else if (k == "px_solo" || k == "px_w8" || k == "px_w16" || k == "px_w32") {
-    ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(1, std::min(255, v));
+    ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(0, std::min(255, v));   // px_solo = 0: the model cuts the classes
+  } else if (k == "px_g1" || k == "px_g8" || k == "px_g16" || k == "px_g32" || k == "px_g64") {
+    ctx->px_g[k == "px_g1" ? 0 : k == "px_g8" ? 1 : k == "px_g16" ? 2 : k == "px_g32" ? 3 : 4] = std::max(0, std::min(100000, v));   // 0.1 us per bounce; 0 = the built-in figure
+  } else if (k == "px_ray_ns") {
+    ctx->px_ray_ns = std::max(0, std::min(100000, v));
   } else if (k == "px_hold") {
     ctx->px_hold = v & 0x1f;
   } else if (k == "px_solo_div") {

@@ -179,6 +179,12 @@ extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
   return g->comms.empty() ? "peer-copy" : "rccl";
 }
 
+// ranks of the RCCL communicator that carries the gather (0: none -- one device, direct stores or peer copies, or RCCL not loaded yet)
+extern "C" int rt_context_rccl_ranks(rt_context *ctx) {
+  if (!ctx || !ctx->group || ctx->group->rccl_failed) return 0;
+  return static_cast<int>(ctx->group->comms.size());
+}
+
 void rti::group_destroy(rt_context *ctx) {
   rt_group *g = ctx ? ctx->group : nullptr;
   if (!g) return;

@@ -643,6 +643,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // (its own instantiation: with the call compiled in, the loop behind it runs 1-5 % slower -- scalar registers saved around
   // the call stay spilled -- so launches without single-pixel tickets use the kernel without it)
   unsigned q_cls = kPxClasses - 1;   // (ORD) class of the ticket in hand
+  unsigned q_base = 0, q_ent = 0;    // (ORD) its first list position; (per lane) the list entry at q_base + lane
   if constexpr (ORD) {
     // the wave's one-pixel tickets (all of them first tickets of the list: the longest chains of the view), each walked by the
     // solo loop; the first ticket of another class goes to the pooled loop
@@ -822,12 +823,16 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 hold = true;
                 __builtin_amdgcn_s_setprio(3);
               }
+              // the ticket's list entries, one per lane, in ONE coalesced load: the refills that consume the ticket take
+              // theirs from the lane that holds it (ds_bpermute) instead of a dependent global load each
+              q_base = q_next;
+              q_ent = (unsigned)lane < q_end - q_next ? p.px_list[q_next + (unsigned)lane] : 0u;
             }
             const unsigned avail = q_end - q_next;
             const unsigned rank = (unsigned)lane_rank(m);
             const unsigned cnt = (unsigned)__popcll(m);
+            const unsigned e = (unsigned)__builtin_amdgcn_ds_bpermute((int)(((q_next - q_base + rank) & 63u) << 2), (int)q_ent);
             if (want & (rank < avail)) {
-              const unsigned e = p.px_list[q_next + rank];
               const int col = (int)(e & 0xffffu), lrow = (int)(e >> 16);
               const int k = lrow >> p.rpt_log2;
               slot = lrow * p.w + col + k * p.out_skip;
@@ -1415,18 +1420,18 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 // neighbours wherever a region has enough pixels of one length), and the header that cuts the list into the ticket classes.
 // Which pixel goes where changes the ORDER in which independent pixels are traced, nothing else.
 // ---------------------------------------------------------------------------------
-constexpr int kPxThreads = 256;
+constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step -- in-order LDS atomics keep a workgroup's pixels of one bin tile by tile
+constexpr int kPxScanThreads = 256;
 constexpr int kPxBins = 64;
 __device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }   // bin = rays traced (saturating)
 
-// the workgroup's tiles [t0, t1): four tiles at a time, one pixel per thread; f(col, lrow, rays)
+// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(col, lrow, rays)
 template <class F>
 __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
   const int ntiles = g.tiles_x * g.tiles_y;
   const int t0 = (int)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-  for (int tb = t0; tb < t1; tb += kPxThreads / 64) {
-    const int tile = tb + ((int)threadIdx.x >> 6), within = (int)threadIdx.x & 63;
-    if (tile >= t1) continue;
+  const int within = (int)threadIdx.x;
+  for (int tile = t0; tile < t1; ++tile) {
     const int ty = tile / g.tiles_x;
     const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
     if (col >= g.w || lrow >= g.rows_local) continue;
@@ -1437,17 +1442,17 @@ __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const 
 // counts[bin * nblocks + block]
 __global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int *counts) {
   __shared__ int hist[kPxBins];
-  if (threadIdx.x < kPxBins) hist[threadIdx.x] = 0;
+  hist[threadIdx.x] = 0;
   __syncthreads();
   px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays)], 1); });
   __syncthreads();
-  if (threadIdx.x < kPxBins) counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+  counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 // one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length); the header
-__global__ __launch_bounds__(kPxThreads) void px_scan_kernel(int *counts, int nblocks, int thr0, int thr1, int thr2, int thr3, int solo_cap, int *hdr) {
-  __shared__ int part[kPxBins][kPxThreads / kPxBins + 1];
+__global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, int nblocks, PxPolicy pol, int *hdr) {
+  constexpr int Q = kPxScanThreads / kPxBins;        // threads per bin: each scans a quarter of the blocks
+  __shared__ int part[kPxBins][Q + 1];
   __shared__ int bin_start[kPxBins + 1];
-  constexpr int Q = kPxThreads / kPxBins;            // threads per bin: each scans a quarter of the blocks
   const int bin = (int)threadIdx.x / Q, q = (int)threadIdx.x % Q;
   const int per = (nblocks + Q - 1) / Q, b0 = min(nblocks, q * per), b1 = min(nblocks, b0 + per);
   int acc = 0;
@@ -1470,11 +1475,35 @@ __global__ __launch_bounds__(kPxThreads) void px_scan_kernel(int *counts, int nb
     // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
     // with longer chains than its own longest.  (pixels of >= t rays = bin_start[t - 1] for t >= 1: the bins above t - 1)
     auto at_least = [&](int t) { return t <= 0 ? a : (t > kPxBins - 1 ? 0 : bin_start[t - 1]); };
-    int t0 = max(thr0, 1);
-    while (t0 < kPxBins && at_least(t0) > solo_cap) ++t0;   // the one-pixel class: at most solo_cap pixels
-    const int t1 = min(thr1, t0), t2 = min(thr2, t1), t3 = min(thr3, t2);
+    int thr[kPxClasses - 1] = {pol.thr[0], pol.thr[1], pol.thr[2], pol.thr[3]};
+    if (pol.thr[0] <= 0) {
+      // the model (rt_device.hpp: PxPolicy).  count[l] = at_least(l) - at_least(l + 1); rays of bin l: l each
+      int maxlen = 1;
+      for (int l = kPxBins - 1; l >= 1; --l)
+        if (at_least(l) > 0) { maxlen = l; break; }
+      const bool solo = pol.solo_cap > 0;
+      long long T = (long long)maxlen * pol.g[solo ? 0 : 1];     // 0.1 us: the longest chain in the narrowest class there is
+      for (int it = 0; it < 4; ++it) {
+        for (int k = 0; k < kPxClasses - 1; ++k) thr[k] = (int)min((long long)kPxBins, T / pol.g[k + 1] + 1);   // class k: chains too long for class k + 1
+        if (!solo) thr[0] = kPxBins;
+        long long busy = 0;                                     // the waves' time, 0.1 us
+        for (int l = 1; l < kPxBins; ++l) {
+          const long long n = at_least(l) - at_least(l + 1);
+          int k = kPxClasses - 1;
+          while (k > 0 && l >= thr[k - 1]) --k;
+          busy += k == kPxClasses - 1 ? n * l * pol.ray_ns / 100 : n * l * pol.g[k] / (1 << px_log2(k));
+        }
+        const long long Tn = max(T, busy / max(1, pol.nwaves));
+        if (Tn <= T) break;
+        T = Tn;
+      }
+    }
+    int t0 = pol.solo_cap > 0 ? max(thr[0], 1) : kPxBins;
+    while (t0 < kPxBins && at_least(t0) > pol.solo_cap) ++t0;   // the one-pixel class: at most solo_cap pixels
+    const int t1 = min(thr[1], t0), t2 = min(thr[2], t1), t3 = min(thr[3], t2);
     int pos[kPxClasses + 1] = {0, at_least(t0), at_least(t1), at_least(t2), at_least(t3), a};
     px_make_header(pos, hdr);
+    hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
   }
   __syncthreads();
   for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
@@ -1482,7 +1511,7 @@ __global__ __launch_bounds__(kPxThreads) void px_scan_kernel(int *counts, int nb
 __global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
                                                             unsigned *list) {
   __shared__ int cursor[kPxBins];
-  if (threadIdx.x < kPxBins) cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
+  cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
   __syncthreads();
   px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
     const int pos = atomicAdd(&cursor[px_bin(rays)], 1);
@@ -1490,15 +1519,14 @@ __global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned cha
   });
 }
 
-hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const int thr[kPxClasses - 1], int solo_cap, unsigned *list, int *hdr,
-                           int *scratch, hipStream_t stream) {
+hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const PxPolicy &pol, unsigned *list, int *hdr, int *scratch, hipStream_t stream) {
   const int ntiles = g.tiles_x * g.tiles_y;
   if (ntiles <= 0) return hipSuccess;
   int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
   while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
   const int nblocks = (ntiles + tpb - 1) / tpb;
   hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch);
-  hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxThreads), 0, stream, scratch, nblocks, thr[0], thr[1], thr[2], thr[3], solo_cap, hdr);
+  hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, hdr);
   hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, list);
   return hipGetLastError();
 }

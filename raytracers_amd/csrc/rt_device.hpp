@@ -280,10 +280,22 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 struct PxGeom {
   int w, rows_local, rpt_log2, out_skip, tiles_x, tiles_y;
 };
+// How the classes are cut.  thr[0] > 0: by hand -- class k (1, 8, 16, 32 pixels per ticket) holds the chains of >= thr[k] rays that no
+// earlier class holds.  thr[0] == 0: from a model of the launch, evaluated on the device from the list's histogram: a wave that carries
+// n rays of equal chain length advances them one bounce per g[k] (units of 0.1 us; k = 0 the solo loop, then 8, 16, 32, 64 rays; they
+// differ by where the scene lives: LDS or L2), so a class may hold chains of up to T / g[k] rays if the frame is to end by T, and T is
+// the larger of what the longest chain takes in the solo loop and what the waves' time adds up to -- rays of class k cost g[k] / width
+// of a wave's time each, those of the 64-pixel class ray_ns -- iterated to a fixed point.
+struct PxPolicy {
+  int thr[kPxClasses - 1];
+  int g[kPxClasses];
+  int ray_ns;        // a wave's time per ray in the 64-pixel class (rays of mixed phases share the wave: cheaper than g[4] / 64, the lockstep figure)
+  int nwaves;
+  int solo_cap;      // the one-pixel class: at most this many pixels (0: no solo loop on this launch)
+};
 constexpr int kPxBlocksMax = 2048;
 constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax; }
-hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const int thr[kPxClasses - 1], int solo_cap, unsigned *list, int *hdr,
-                           int *scratch, hipStream_t stream);
+hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const PxPolicy &pol, unsigned *list, int *hdr, int *scratch, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
 

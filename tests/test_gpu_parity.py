@@ -1031,6 +1031,8 @@ def test_multi_device_real_devices(R):
             assert all(cks(buf[f]) == bench.FRAME_CHECKSUM[(scene, h, w)] for f in range(6)), gather
             ps.free()
         assert mc.gather_mode in {3: ("direct-store",), 2: ("rccl", "peer-copy"), 1: ("peer-copy",), 0: ("direct-store",)}[gather]
+        if gather == 2 and mc.gather_mode == "rccl":   # distinct devices: one communicator rank per device carried the frames
+            assert mc.rccl_ranks == n
     mc.close()
 
 
