@@ -486,7 +486,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // recomputes every frame (testing aid).
       // (a view whose tiles were first recorded by a batch has no per-pixel record yet: its first single frame records again)
       const bool px_can = ctx->pixel_order != 0 && nframes == 1 && to->px_list != nullptr && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-                          to->cost_px_bytes >= static_cast<size_t>(h) * w && (p.nshards == 1 || p.interleave);
+                          to->cost_px_bytes >= static_cast<size_t>(h) * w && (p.nshards == 1 || p.interleave) &&
+                          (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
       const bool rerecord = !to->valid || ctx->adaptive_order == 2 || (px_can && !to->px_valid);
       p.cost = rerecord ? to->cost : nullptr;
       p.cost_px = rerecord && px_can ? to->cost_px : nullptr;
@@ -521,7 +522,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
     if (to && to->valid && to->px_valid && nframes == 1 && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 &&
         (p.nshards == 1 || p.interleave) && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4))) {
+        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles))) {
       p.px_list = to->px_list;
       p.px_hdr = reinterpret_cast<const int *>(to->px_list + to->px_elems);
       p.px_hold = ctx->px_hold;
@@ -560,9 +561,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
         // the model's bounce cadences (0.1 us; measured, profiles/r05/exp): a scene that lives in LDS, one that is read from L2
         const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-        static const int g_lds[5] = {25, 45, 65, 100, 160}, g_l2[5] = {45, 70, 100, 190, 330};
+        static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 95, 135, 200, 330};
         for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
         pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 300;
+        pol.coarse = ctx->px_coarse;
         pol.nwaves = pl.grid_full * pl.waves;
         pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
         RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
@@ -772,6 +774,10 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(0, std::min(255, v));   // px_solo = 0: the model cuts the classes
   } else if (k == "px_g1" || k == "px_g8" || k == "px_g16" || k == "px_g32" || k == "px_g64") {
     ctx->px_g[k == "px_g1" ? 0 : k == "px_g8" ? 1 : k == "px_g16" ? 2 : k == "px_g32" ? 3 : 4] = std::max(0, std::min(100000, v));   // 0.1 us per bounce; 0 = the built-in figure
+  } else if (k == "px_coarse") {
+    ctx->px_coarse = v != 0;
+  } else if (k == "px_max_tiles") {
+    ctx->px_max_tiles = std::max(0, v);
   } else if (k == "px_ray_ns") {
     ctx->px_ray_ns = std::max(0, std::min(100000, v));
   } else if (k == "px_hold") {

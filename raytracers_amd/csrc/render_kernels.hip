@@ -643,6 +643,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // (its own instantiation: with the call compiled in, the loop behind it runs 1-5 % slower -- scalar registers saved around
   // the call stay spilled -- so launches without single-pixel tickets use the kernel without it)
   unsigned q_cls = kPxClasses - 1;   // (ORD) class of the ticket in hand
+  int cnt_ahead = 0;                 // (ORD, per lane) the slot's counter of outstanding inner-node items, read ahead of the operation choice
   unsigned q_base = 0, q_ent = 0;    // (ORD) its first list position; (per lane) the list entry at q_base + lane
   if constexpr (ORD) {
     // the wave's one-pixel tickets (all of them first tickets of the list: the longest chains of the view), each walked by the
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     }
   }
   for (;;) {
+    bool shaded = false;   // (ORD) this iteration was a SHADE: no other operation, straight to the loop's tail
     RT_MARK("CHOICE_BEGIN");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
@@ -743,7 +745,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
      if (nbox == 0 || (nbox < p.look_max && (int)__popcll(m_live | bal(vacant)) >= thr)) {
       // With leaf items pending `done` over-estimates (the counter covers inner-node items only): it
       // then only decides whether to drain the leaf list now.
-      const bool done = (pix >= 0) & (wcnt[lane] == 0);
+      // (ORD: the counter was read at the tail of the operation before -- its LDS round trip ran under the loop head's scalar code)
+      const bool done = (pix >= 0) & ((ORD ? cnt_ahead : wcnt[lane]) == 0);
       const int ns = __popcll(bal(done | vacant));
       if (ns >= thr || nbox == 0) {
         if (nleaf > 0) {
@@ -1014,13 +1017,15 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           }
           if (STATS) tr_cyc[4] += clock64() - tr_s0;
           RT_MARK("SHADE_END");
-          continue;
+          if constexpr (ORD) shaded = true; else continue;
         }
       }
      }
      leaf_op = drain | (nbox == 0);
     }
-    if (leaf_op) {
+    if (ORD && shaded) {
+      // (nothing: the tail below)
+    } else if (leaf_op) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       RT_MARK("LEAF_BEGIN");
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
@@ -1211,6 +1216,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         else tr_cyc[2] += dt;
       }
     }
+    // ORD: the slots' counters for the NEXT operation choice, read here, at the loop's tail -- behind this operation's ds_add (a wave's
+    // LDS operations complete in order) and ahead of the loop head's scalar code, which runs under the LDS round trip.  (One
+    // definition per iteration: a conditional read makes the register allocator copy the value at the back edge, and wait for it there.)
+    if constexpr (ORD) cnt_ahead = wcnt[lane];
   }
   if constexpr (DONATE) {
     // This wave is finished: it waits for rays of its siblings until every wave of the workgroup has left the loop.
@@ -1423,7 +1432,15 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step -- in-order LDS atomics keep a workgroup's pixels of one bin tile by tile
 constexpr int kPxScanThreads = 256;
 constexpr int kPxBins = 64;
-__device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }   // bin = rays traced (saturating)
+// bin = rays traced (saturating) -- except that the short chains, the bulk of every frame, fall into three coarse bins (chains of up to 2,
+// 6 and 12 rays, each counted as its longest): their pixels keep the raster order of the tiles inside a bin, so a wave's 64 rays differ
+// in length as a tile's do.  Rays of EQUAL length finish their folds in the same operations, the wave runs from one full refill to the
+// next in lockstep and its box operations thin out at every generation's ends: the exact sort cost a work-bound frame 11-15 %
+// (irreg 4000 x 4000 1.95 -> 2.17-2.24 ms, profiles/r05/exp/e1, e2).
+__device__ __forceinline__ int px_bin(int rays, int coarse) {
+  const int b = rays < kPxBins - 1 ? rays : kPxBins - 1;
+  return (coarse && b <= 12) ? (b <= 2 ? 2 : b <= 6 ? 6 : 12) : b;
+}
 
 // the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(col, lrow, rays)
 template <class F>
@@ -1440,11 +1457,11 @@ __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const 
   }
 }
 // counts[bin * nblocks + block]
-__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int *counts) {
+__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int coarse, int *counts) {
   __shared__ int hist[kPxBins];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays)], 1); });
+  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays, coarse)], 1); });
   __syncthreads();
   counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
@@ -1508,13 +1525,13 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
   __syncthreads();
   for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
 }
-__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
-                                                            unsigned *list) {
+__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int coarse,
+                                                            const int *starts, unsigned *list) {
   __shared__ int cursor[kPxBins];
   cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
   __syncthreads();
   px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
-    const int pos = atomicAdd(&cursor[px_bin(rays)], 1);
+    const int pos = atomicAdd(&cursor[px_bin(rays, coarse)], 1);
     list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
   });
 }
@@ -1525,9 +1542,9 @@ hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const 
   int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
   while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
   const int nblocks = (ntiles + tpb - 1) / tpb;
-  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch);
+  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, pol.coarse, scratch);
   hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, hdr);
-  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, list);
+  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, pol.coarse, scratch, list);
   return hipGetLastError();
 }
 
