@@ -561,10 +561,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
         // the model's bounce cadences (0.1 us; measured, profiles/r05/exp): a scene that lives in LDS, one that is read from L2
         const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-        static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 95, 135, 200, 330};
+        static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
         for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
         pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 300;
-        pol.coarse = ctx->px_coarse;
+        pol.hybrid = ctx->px_hybrid;
         pol.nwaves = pl.grid_full * pl.waves;
         pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
         RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
@@ -774,8 +774,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(0, std::min(255, v));   // px_solo = 0: the model cuts the classes
   } else if (k == "px_g1" || k == "px_g8" || k == "px_g16" || k == "px_g32" || k == "px_g64") {
     ctx->px_g[k == "px_g1" ? 0 : k == "px_g8" ? 1 : k == "px_g16" ? 2 : k == "px_g32" ? 3 : 4] = std::max(0, std::min(100000, v));   // 0.1 us per bounce; 0 = the built-in figure
-  } else if (k == "px_coarse") {
-    ctx->px_coarse = v != 0;
+  } else if (k == "px_hybrid") {
+    ctx->px_hybrid = v != 0;
   } else if (k == "px_max_tiles") {
     ctx->px_max_tiles = std::max(0, v);
   } else if (k == "px_ray_ns") {

@@ -643,7 +643,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   // (its own instantiation: with the call compiled in, the loop behind it runs 1-5 % slower -- scalar registers saved around
   // the call stay spilled -- so launches without single-pixel tickets use the kernel without it)
   unsigned q_cls = kPxClasses - 1;   // (ORD) class of the ticket in hand
-  int cnt_ahead = 0;                 // (ORD, per lane) the slot's counter of outstanding inner-node items, read ahead of the operation choice
   unsigned q_base = 0, q_ent = 0;    // (ORD) its first list position; (per lane) the list entry at q_base + lane
   if constexpr (ORD) {
     // the wave's one-pixel tickets (all of them first tickets of the list: the longest chains of the view), each walked by the
@@ -713,7 +712,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
     }
   }
   for (;;) {
-    bool shaded = false;   // (ORD) this iteration was a SHADE: no other operation, straight to the loop's tail
     RT_MARK("CHOICE_BEGIN");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
@@ -745,8 +743,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
      if (nbox == 0 || (nbox < p.look_max && (int)__popcll(m_live | bal(vacant)) >= thr)) {
       // With leaf items pending `done` over-estimates (the counter covers inner-node items only): it
       // then only decides whether to drain the leaf list now.
-      // (ORD: the counter was read at the tail of the operation before -- its LDS round trip ran under the loop head's scalar code)
-      const bool done = (pix >= 0) & ((ORD ? cnt_ahead : wcnt[lane]) == 0);
+      const bool done = (pix >= 0) & (wcnt[lane] == 0);
       const int ns = __popcll(bal(done | vacant));
       if (ns >= thr || nbox == 0) {
         if (nleaf > 0) {
@@ -1017,15 +1014,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           }
           if (STATS) tr_cyc[4] += clock64() - tr_s0;
           RT_MARK("SHADE_END");
-          if constexpr (ORD) shaded = true; else continue;
+          continue;
         }
       }
      }
      leaf_op = drain | (nbox == 0);
     }
-    if (ORD && shaded) {
-      // (nothing: the tail below)
-    } else if (leaf_op) {
+    if (leaf_op) {
       // ---- LEAF: up to 64 (slot, sphere) items ----
       RT_MARK("LEAF_BEGIN");
       if (STATS) { tr_ops[1]++; tr_items[1] += nleaf < 64 ? nleaf : 64; }
@@ -1216,10 +1211,6 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         else tr_cyc[2] += dt;
       }
     }
-    // ORD: the slots' counters for the NEXT operation choice, read here, at the loop's tail -- behind this operation's ds_add (a wave's
-    // LDS operations complete in order) and ahead of the loop head's scalar code, which runs under the LDS round trip.  (One
-    // definition per iteration: a conditional read makes the register allocator copy the value at the back edge, and wait for it there.)
-    if constexpr (ORD) cnt_ahead = wcnt[lane];
   }
   if constexpr (DONATE) {
     // This wave is finished: it waits for rays of its siblings until every wave of the workgroup has left the loop.
@@ -1432,17 +1423,11 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step -- in-order LDS atomics keep a workgroup's pixels of one bin tile by tile
 constexpr int kPxScanThreads = 256;
 constexpr int kPxBins = 64;
-// bin = rays traced (saturating) -- except that the short chains, the bulk of every frame, fall into three coarse bins (chains of up to 2,
-// 6 and 12 rays, each counted as its longest): their pixels keep the raster order of the tiles inside a bin, so a wave's 64 rays differ
-// in length as a tile's do.  Rays of EQUAL length finish their folds in the same operations, the wave runs from one full refill to the
-// next in lockstep and its box operations thin out at every generation's ends: the exact sort cost a work-bound frame 11-15 %
-// (irreg 4000 x 4000 1.95 -> 2.17-2.24 ms, profiles/r05/exp/e1, e2).
-__device__ __forceinline__ int px_bin(int rays, int coarse) {
-  const int b = rays < kPxBins - 1 ? rays : kPxBins - 1;
-  return (coarse && b <= 12) ? (b <= 2 ? 2 : b <= 6 ? 6 : 12) : b;
-}
+// bin = rays traced (saturating)
+__device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }
 
-// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(col, lrow, rays)
+// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(in_image, col, lrow, rays) is called by ALL lanes of the
+// wave for every tile (lanes outside a ragged image: in_image false, rays 0): f may use wave-wide operations
 template <class F>
 __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
   const int ntiles = g.tiles_x * g.tiles_y;
@@ -1451,21 +1436,43 @@ __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const 
   for (int tile = t0; tile < t1; ++tile) {
     const int ty = tile / g.tiles_x;
     const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
-    if (col >= g.w || lrow >= g.rows_local) continue;
+    const bool in = col < g.w && lrow < g.rows_local;
     const size_t idx = (size_t)lrow * g.w + col + (size_t)(lrow >> g.rpt_log2) * (size_t)g.out_skip;
-    f(col, lrow, (int)cost_px[idx]);
+    f(in, col, lrow, in ? (int)cost_px[idx] : 0);
   }
 }
-// counts[bin * nblocks + block]
-__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int coarse, int *counts) {
+__device__ __forceinline__ int wave_max(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+// The bin a pixel is sorted into.  Chains of >= t3 rays (the classes of fewer than 64 pixels per ticket): their own length.  The BULK
+// (hdr[7] = t3, cut by px_scan_kernel; hybrid lists only): the longest bulk chain of the pixel's TILE -- a tile's bulk pixels stay
+// together, in tile order, tiles with longer remaining chains first: what the tile order does, minus the long chains.  A wave's 64
+// rays then differ in length as a tile's do; rays of EQUAL length finish their folds in the same operations, the wave runs from one
+// full refill to the next in lockstep and its box operations thin out at every generation's ends (the exact sort: irreg 1000 x 1000
+// 0.295 ms against 0.258 with mixed lengths, profiles/r05/exp/e3).
+__device__ __forceinline__ int px_sort_bin(bool in, int rays, int t3) {
+  const int b = px_bin(rays);
+  const bool bulk = in && b < t3;
+  const int m = wave_max(bulk ? b : 0);      // (all lanes)
+  return bulk ? m : b;
+}
+// counts[bin * nblocks + block]; t3_hdr == nullptr: every pixel by its own length (the first pass, and the exact list)
+__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *t3_hdr,
+                                                            int *counts) {
   __shared__ int hist[kPxBins];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays, coarse)], 1); });
+  const int t3 = t3_hdr ? t3_hdr[7] : 0;
+  px_for_each(cost_px, g, tiles_per_block, [&](bool in, int, int, int rays) {
+    const int b = px_sort_bin(in, rays, t3);
+    if (in) atomicAdd(&hist[b], 1);
+  });
   __syncthreads();
   counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
-// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length); the header
+// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length).  hdr != nullptr (first
+// pass): the header from the histogram -- the model, the classes' cuts; hdr == nullptr (second pass of a hybrid list: bins by tile).
 __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, int nblocks, PxPolicy pol, int *hdr) {
   constexpr int Q = kPxScanThreads / kPxBins;        // threads per bin: each scans a quarter of the blocks
   __shared__ int part[kPxBins][Q + 1];
@@ -1489,6 +1496,7 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
       a += tot;
     }
     bin_start[kPxBins] = a;                        // all pixels
+    if (hdr != nullptr) {
     // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
     // with longer chains than its own longest.  (pixels of >= t rays = bin_start[t - 1] for t >= 1: the bins above t - 1)
     auto at_least = [&](int t) { return t <= 0 ? a : (t > kPxBins - 1 ? 0 : bin_start[t - 1]); };
@@ -1521,18 +1529,24 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
     int pos[kPxClasses + 1] = {0, at_least(t0), at_least(t1), at_least(t2), at_least(t3), a};
     px_make_header(pos, hdr);
     hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
+    hdr[7] = pol.hybrid ? t3 : 0;                               // hybrid list: chains of fewer rays are the bulk
+    }
   }
   __syncthreads();
   for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
 }
-__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int coarse,
+__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *t3_hdr,
                                                             const int *starts, unsigned *list) {
   __shared__ int cursor[kPxBins];
   cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
   __syncthreads();
-  px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
-    const int pos = atomicAdd(&cursor[px_bin(rays, coarse)], 1);
-    list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
+  const int t3 = t3_hdr ? t3_hdr[7] : 0;
+  px_for_each(cost_px, g, tiles_per_block, [&](bool in, int col, int lrow, int rays) {
+    const int b = px_sort_bin(in, rays, t3);
+    if (in) {
+      const int pos = atomicAdd(&cursor[b], 1);
+      list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
+    }
   });
 }
 
@@ -1542,9 +1556,18 @@ hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const 
   int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
   while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
   const int nblocks = (ntiles + tpb - 1) / tpb;
-  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, pol.coarse, scratch);
+  // pass 1: every pixel by its own length -> the histogram, the model's cuts, the header (and, for an exact list, the places)
+  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, (const int *)nullptr, scratch);
   hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, hdr);
-  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, pol.coarse, scratch, list);
+  const int *t3_hdr = nullptr;
+  if (pol.hybrid) {
+    // pass 2 (hybrid list): the bulk by its tile's longest bulk chain.  The long chains' bins are the same as in pass 1 (their
+    // places do not move: the bulk's bins all lie below t3), the total is the same, so the header stands.
+    t3_hdr = hdr;
+    hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, t3_hdr, scratch);
+    hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, (int *)nullptr);
+  }
+  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, t3_hdr, scratch, list);
   return hipGetLastError();
 }
 
