@@ -522,11 +522,13 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
     if (to && to->valid && to->px_valid && nframes == 1 && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 &&
         (p.nshards == 1 || p.interleave) && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles))) {
+        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
+                                   (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {
       p.px_list = to->px_list;
       p.px_hdr = reinterpret_cast<const int *>(to->px_list + to->px_elems);
       p.px_hold = ctx->px_hold;
       p.cold = 0;
+      p.solo = (to->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
       if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
         const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
         const int il = ns > 1 && xq == 2;
@@ -564,9 +566,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
         for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
         pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 300;
-        pol.hybrid = ctx->px_hybrid;
         pol.nwaves = pl.grid_full * pl.waves;
-        pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+        // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel without
+        // the solo call is 1-5 % faster)
+        pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+        to->px_solo = pol.solo_cap > 0;
         RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
                                          ctx->stream));
         to->px_valid = true;
@@ -774,8 +778,6 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_thr[k == "px_solo" ? 0 : k == "px_w8" ? 1 : k == "px_w16" ? 2 : 3] = std::max(0, std::min(255, v));   // px_solo = 0: the model cuts the classes
   } else if (k == "px_g1" || k == "px_g8" || k == "px_g16" || k == "px_g32" || k == "px_g64") {
     ctx->px_g[k == "px_g1" ? 0 : k == "px_g8" ? 1 : k == "px_g16" ? 2 : k == "px_g32" ? 3 : 4] = std::max(0, std::min(100000, v));   // 0.1 us per bounce; 0 = the built-in figure
-  } else if (k == "px_hybrid") {
-    ctx->px_hybrid = v != 0;
   } else if (k == "px_max_tiles") {
     ctx->px_max_tiles = std::max(0, v);
   } else if (k == "px_ray_ns") {

@@ -550,7 +550,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
-  static_assert(!ORD || (SOLO && TAIL == 0 && !STATS), "ORD: the solo prologue, no tail variant");
+  static_assert(!ORD || (TAIL == 0 && !STATS), "ORD: no tail variant");
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -647,7 +647,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   if constexpr (ORD) {
     // the wave's one-pixel tickets (all of them first tickets of the list: the longest chains of the view), each walked by the
     // solo loop; the first ticket of another class goes to the pooled loop
-    const bool solo_ok = p.solo && p.tl_log2 == kTreeletDepth;
+    // (SOLO false: the instantiation for lists without a one-pixel class -- launches too large for the solo loop to matter: the
+    // call's saved scalar registers cost the loop behind it 1-5 %)
+    const bool solo_ok = SOLO && p.solo && p.tl_log2 == kTreeletDepth;
     for (;;) {
       TicketSpan sp;
       const QueueConst qc = queue_const();
@@ -668,14 +670,16 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         q_enter = true;
         break;
       }
-      const unsigned e = p.px_list[sp.q_next];      // uniform (scalar) load
-      const int col = (int)(e & 0xffffu), lrow = (int)(e >> 16);
-      const int k = lrow >> p.rpt_log2;
-      const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
-      Ray pr;
-      primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
-      solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
-                 pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, (lrow >> 3) * p.tiles_x + (col >> 3));
+      if constexpr (SOLO) {
+        const unsigned e = p.px_list[sp.q_next];      // uniform (scalar) load
+        const int col = (int)(e & 0xffffu), lrow = (int)(e >> 16);
+        const int k = lrow >> p.rpt_log2;
+        const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
+        Ray pr;
+        primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
+        solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+                   pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, (lrow >> 3) * p.tiles_x + (col >> 3));
+      }
     }
   }
   if (!ORD && SOLO && deep_on && p.deep_split == 6 && p.tl_log2 == kTreeletDepth) {
@@ -1416,8 +1420,10 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 // Pixel list of a view (rt_device.hpp: pixel tickets).  The view's first frame stores, next to every pixel, the number of
 // rays its chain took (p.cost_px, one byte, indexed like the framebuffer); these kernels turn that record into the list the
 // view's later single frames draw their tickets from: the part's pixels as (local row << 16 | column), sorted by chain length,
-// longest first (a counting sort over 64 bins; a workgroup's pixels of one bin stay together, so a ticket's pixels are
+// longest first (a counting sort over 64 bins; a workgroup's pixels of one bin stay together, tile by tile, so a ticket's pixels are
 // neighbours wherever a region has enough pixels of one length), and the header that cuts the list into the ticket classes.
+// (Measured and not kept, profiles/r05/README.md: the bulk of the list in tile order instead of sorted by its own lengths -- a wave's
+// rays then differ in length as a tile's do -- rendered irreg the same and rgbbox 1000 x 1000 5-7 % slower than the plain sort.)
 // Which pixel goes where changes the ORDER in which independent pixels are traced, nothing else.
 // ---------------------------------------------------------------------------------
 constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step -- in-order LDS atomics keep a workgroup's pixels of one bin tile by tile
@@ -1426,8 +1432,7 @@ constexpr int kPxBins = 64;
 // bin = rays traced (saturating)
 __device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }
 
-// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(in_image, col, lrow, rays) is called by ALL lanes of the
-// wave for every tile (lanes outside a ragged image: in_image false, rays 0): f may use wave-wide operations
+// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(col, lrow, rays)
 template <class F>
 __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
   const int ntiles = g.tiles_x * g.tiles_y;
@@ -1436,43 +1441,22 @@ __device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const 
   for (int tile = t0; tile < t1; ++tile) {
     const int ty = tile / g.tiles_x;
     const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
-    const bool in = col < g.w && lrow < g.rows_local;
+    if (col >= g.w || lrow >= g.rows_local) continue;
     const size_t idx = (size_t)lrow * g.w + col + (size_t)(lrow >> g.rpt_log2) * (size_t)g.out_skip;
-    f(in, col, lrow, in ? (int)cost_px[idx] : 0);
+    f(col, lrow, (int)cost_px[idx]);
   }
 }
-__device__ __forceinline__ int wave_max(int v) {
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
-}
-// The bin a pixel is sorted into.  Chains of >= t3 rays (the classes of fewer than 64 pixels per ticket): their own length.  The BULK
-// (hdr[7] = t3, cut by px_scan_kernel; hybrid lists only): the longest bulk chain of the pixel's TILE -- a tile's bulk pixels stay
-// together, in tile order, tiles with longer remaining chains first: what the tile order does, minus the long chains.  A wave's 64
-// rays then differ in length as a tile's do; rays of EQUAL length finish their folds in the same operations, the wave runs from one
-// full refill to the next in lockstep and its box operations thin out at every generation's ends (the exact sort: irreg 1000 x 1000
-// 0.295 ms against 0.258 with mixed lengths, profiles/r05/exp/e3).
-__device__ __forceinline__ int px_sort_bin(bool in, int rays, int t3) {
-  const int b = px_bin(rays);
-  const bool bulk = in && b < t3;
-  const int m = wave_max(bulk ? b : 0);      // (all lanes)
-  return bulk ? m : b;
-}
-// counts[bin * nblocks + block]; t3_hdr == nullptr: every pixel by its own length (the first pass, and the exact list)
-__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *t3_hdr,
-                                                            int *counts) {
+// counts[bin * nblocks + block]
+__global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int *counts) {
   __shared__ int hist[kPxBins];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const int t3 = t3_hdr ? t3_hdr[7] : 0;
-  px_for_each(cost_px, g, tiles_per_block, [&](bool in, int, int, int rays) {
-    const int b = px_sort_bin(in, rays, t3);
-    if (in) atomicAdd(&hist[b], 1);
-  });
+  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays)], 1); });
   __syncthreads();
   counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
-// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length).  hdr != nullptr (first
-// pass): the header from the histogram -- the model, the classes' cuts; hdr == nullptr (second pass of a hybrid list: bins by tile).
+// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length); the header:
+// the model evaluated on the histogram, the classes' cuts
 __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, int nblocks, PxPolicy pol, int *hdr) {
   constexpr int Q = kPxScanThreads / kPxBins;        // threads per bin: each scans a quarter of the blocks
   __shared__ int part[kPxBins][Q + 1];
@@ -1496,7 +1480,6 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
       a += tot;
     }
     bin_start[kPxBins] = a;                        // all pixels
-    if (hdr != nullptr) {
     // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
     // with longer chains than its own longest.  (pixels of >= t rays = bin_start[t - 1] for t >= 1: the bins above t - 1)
     auto at_least = [&](int t) { return t <= 0 ? a : (t > kPxBins - 1 ? 0 : bin_start[t - 1]); };
@@ -1529,24 +1512,18 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
     int pos[kPxClasses + 1] = {0, at_least(t0), at_least(t1), at_least(t2), at_least(t3), a};
     px_make_header(pos, hdr);
     hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
-    hdr[7] = pol.hybrid ? t3 : 0;                               // hybrid list: chains of fewer rays are the bulk
-    }
   }
   __syncthreads();
   for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
 }
-__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *t3_hdr,
-                                                            const int *starts, unsigned *list) {
+__global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
+                                                            unsigned *list) {
   __shared__ int cursor[kPxBins];
   cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
   __syncthreads();
-  const int t3 = t3_hdr ? t3_hdr[7] : 0;
-  px_for_each(cost_px, g, tiles_per_block, [&](bool in, int col, int lrow, int rays) {
-    const int b = px_sort_bin(in, rays, t3);
-    if (in) {
-      const int pos = atomicAdd(&cursor[b], 1);
-      list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
-    }
+  px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
+    const int pos = atomicAdd(&cursor[px_bin(rays)], 1);
+    list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
   });
 }
 
@@ -1556,18 +1533,9 @@ hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const 
   int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
   while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
   const int nblocks = (ntiles + tpb - 1) / tpb;
-  // pass 1: every pixel by its own length -> the histogram, the model's cuts, the header (and, for an exact list, the places)
-  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, (const int *)nullptr, scratch);
+  hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch);
   hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, hdr);
-  const int *t3_hdr = nullptr;
-  if (pol.hybrid) {
-    // pass 2 (hybrid list): the bulk by its tile's longest bulk chain.  The long chains' bins are the same as in pass 1 (their
-    // places do not move: the bulk's bins all lie below t3), the total is the same, so the header stands.
-    t3_hdr = hdr;
-    hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, t3_hdr, scratch);
-    hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, (int *)nullptr);
-  }
-  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, t3_hdr, scratch, list);
+  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, list);
   return hipGetLastError();
 }
 
@@ -1691,6 +1659,8 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   // (ORD: pixel tickets; workgroups of 16 waves only)
   if (p.px_hdr != nullptr) {
     if (waves_per_wg != 16 || p.nframes != 1) return hipErrorInvalidValue;
+    if (!p.solo)   // (a list without a one-pixel class)
+      return all_lds ? launch_pooled_t<1024, true, false, false, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 0, true>(p, grid, stream);
     return all_lds ? launch_pooled_t<1024, true, false, true, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, false, true, 0, true>(p, grid, stream);
   }
   // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
@@ -1733,6 +1703,8 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 1>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 0, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)px_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_place_kernel);

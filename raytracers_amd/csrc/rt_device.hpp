@@ -292,7 +292,6 @@ struct PxPolicy {
   int ray_ns;        // a wave's time per ray in the 64-pixel class (rays of mixed phases share the wave: cheaper than g[4] / 64, the lockstep figure)
   int nwaves;
   int solo_cap;      // the one-pixel class: at most this many pixels (0: no solo loop on this launch)
-  int hybrid;        // 1: only the chains of the classes below 64 pixels per ticket are sorted by their own length; the bulk keeps the TILE order (a tile's bulk pixels together, tiles by their longest bulk chain)
 };
 constexpr int kPxBlocksMax = 2048;
 constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax; }

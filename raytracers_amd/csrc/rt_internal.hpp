@@ -54,7 +54,6 @@ struct rt_context {
   int pixel_order = 1;      // pooled family: an ordered single frame draws its tickets from the view's PIXEL list (rt_device.hpp: pixel tickets; the ORD instantiation). 0 = tile tickets only; 1 = where measured faster (api.cpp); 2 = whenever the view has a list (testing)
   int px_thr[4] = {0, 24, 14, 9};    // ... the list's classes: [0] == 0 (default): cut by the model of rt_device.hpp (PxPolicy) from the view's histogram; else chains of >= px_thr[0] rays go out one pixel per ticket (solo loop), >= [1] 8 per ticket, >= [2] 16, >= [3] 32, the rest 64
   int px_g[5] = {0, 0, 0, 0, 0};     // ... the model's bounce cadences for 1 / 8 / 16 / 32 / 64 rays per wave, 0.1 us (0: the built-in figures, by where the scene lives)
-  int px_hybrid = 1;        // ... the list's bulk (the 64-pixel class) keeps the tile order -- a tile's bulk pixels together, tiles by their longest bulk chain -- and only the long chains are sorted by their own length (0: every pixel by its own length)
   int px_max_tiles = 65536; // ... pixel_order = 1: launches of more tiles than this keep the tile tickets (a work-bound frame gains nothing from the list)
   int px_ray_ns = 0;        // ... and a wave's time per ray of the 64-pixel class, ns (0: 300)
   int px_hold = 0xf;        // ... bit k: a wave holding a ticket of class k does not refill (classes 0 .. 3: 1, 8, 16, 32 pixels)
@@ -119,6 +118,7 @@ struct TileOrder {
   unsigned *px_list = nullptr;        // [px_elems] the part's pixels, longest chains first; then the header (rtk::kPxHdrInts)
   size_t cost_px_bytes = 0, px_elems = 0;
   bool px_valid = false;
+  bool px_solo = false;               // the list was cut with a one-pixel class (the SOLO flavour of the ORD instantiation renders it)
   uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
   bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
   int classes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -211,6 +211,32 @@ KERNEL(k_div_fixup, 16, 8, R8("v_div_fixup_f32", ",v36,v37"))
 KERNEL(k_mbcnt, 16, 8, "v_mbcnt_lo_u32_b32 v20,s60,0\nv_mbcnt_hi_u32_b32 v20,s61,v20\nv_mbcnt_lo_u32_b32 v21,s62,0\nv_mbcnt_hi_u32_b32 v21,s63,v21\n"
                        "v_mbcnt_lo_u32_b32 v22,s64,0\nv_mbcnt_hi_u32_b32 v22,s65,v22\nv_mbcnt_lo_u32_b32 v23,s66,0\nv_mbcnt_hi_u32_b32 v23,s67,v23")
 KERNEL(k_lshl_add, 16, 8, R8("v_lshl_add_u32", ",2,v38"))
+// round 5: candidates for the box test's sign swap and the append's address selects (is there a 2-cycle form of a select?)
+KERNEL(k_bfi, 16, 8, R8("v_bfi_b32", ",v38,v36"))
+KERNEL(k_xor, 16, 8, R8("v_xor_b32", ",v38"))
+KERNEL(k_or, 16, 8, R8("v_or_b32", ",v38"))
+KERNEL(k_lshlrev, 16, 8, "v_lshlrev_b32 v20,2,v20\nv_lshlrev_b32 v21,2,v21\nv_lshlrev_b32 v22,2,v22\nv_lshlrev_b32 v23,2,v23\n"
+                         "v_lshlrev_b32 v24,2,v24\nv_lshlrev_b32 v25,2,v25\nv_lshlrev_b32 v26,2,v26\nv_lshlrev_b32 v27,2,v27")
+KERNEL(k_ashrrev, 16, 8, "v_ashrrev_i32 v20,31,v20\nv_ashrrev_i32 v21,31,v21\nv_ashrrev_i32 v22,31,v22\nv_ashrrev_i32 v23,31,v23\n"
+                         "v_ashrrev_i32 v24,31,v24\nv_ashrrev_i32 v25,31,v25\nv_ashrrev_i32 v26,31,v26\nv_ashrrev_i32 v27,31,v27")
+KERNEL(k_max, 16, 8, R8("v_max_f32", ",v36"))
+KERNEL(k_med3, 16, 8, R8("v_med3_f32", ",v36,v37"))
+KERNEL(k_perm, 16, 8, R8("v_perm_b32", ",v36,v38"))
+KERNEL(k_and_or, 16, 8, R8("v_and_or_b32", ",v38,v39"))
+KERNEL(k_lshl_or, 16, 8, R8("v_lshl_or_b32", ",2,v38"))
+KERNEL(k_add3, 16, 8, R8("v_add3_u32", ",v38,v39"))
+KERNEL(k_sub_u32, 16, 8, R8("v_sub_u32", ",v38"))
+KERNEL(k_min_u32, 16, 8, R8("v_min_u32", ",v38"))
+KERNEL(k_fmac, 16, 8, "v_fmac_f32 v20,v36,v37\nv_fmac_f32 v21,v36,v37\nv_fmac_f32 v22,v36,v37\nv_fmac_f32 v23,v36,v37\n"
+                      "v_fmac_f32 v24,v36,v37\nv_fmac_f32 v25,v36,v37\nv_fmac_f32 v26,v36,v37\nv_fmac_f32 v27,v36,v37")
+KERNEL(k_pk_fma, 16, 8, "v_pk_fma_f32 v[20:21],v[20:21],v[36:37],v[36:37]\nv_pk_fma_f32 v[22:23],v[22:23],v[36:37],v[36:37]\n"
+                        "v_pk_fma_f32 v[24:25],v[24:25],v[36:37],v[36:37]\nv_pk_fma_f32 v[26:27],v[26:27],v[36:37],v[36:37]\n"
+                        "v_pk_fma_f32 v[28:29],v[28:29],v[36:37],v[36:37]\nv_pk_fma_f32 v[30:31],v[30:31],v[36:37],v[36:37]\n"
+                        "v_pk_fma_f32 v[32:33],v[32:33],v[36:37],v[36:37]\nv_pk_fma_f32 v[34:35],v[34:35],v[36:37],v[36:37]")
+KERNEL(k_pk_mov, 16, 8, "v_pk_mov_b32 v[20:21],v[36:37],v[36:37]\nv_pk_mov_b32 v[22:23],v[36:37],v[36:37]\n"
+                        "v_pk_mov_b32 v[24:25],v[36:37],v[36:37]\nv_pk_mov_b32 v[26:27],v[36:37],v[36:37]\n"
+                        "v_pk_mov_b32 v[28:29],v[36:37],v[36:37]\nv_pk_mov_b32 v[30:31],v[36:37],v[36:37]\n"
+                        "v_pk_mov_b32 v[32:33],v[36:37],v[36:37]\nv_pk_mov_b32 v[34:35],v[36:37],v[36:37]")
 KERNEL(k_mov, 16, 8, "v_mov_b32 v20,v36\nv_mov_b32 v21,v36\nv_mov_b32 v22,v36\nv_mov_b32 v23,v36\nv_mov_b32 v24,v36\nv_mov_b32 v25,v36\nv_mov_b32 v26,v36\nv_mov_b32 v27,v36")
 KERNEL(k_readfirstlane, 16, 8, "v_readfirstlane_b32 s60,v20\nv_readfirstlane_b32 s61,v21\nv_readfirstlane_b32 s62,v22\nv_readfirstlane_b32 s63,v23\n"
                                "v_readfirstlane_b32 s64,v24\nv_readfirstlane_b32 s65,v25\nv_readfirstlane_b32 s66,v26\nv_readfirstlane_b32 s67,v27")
@@ -279,6 +305,9 @@ int main(int argc, char **argv) {
       OP(k_and, 0, false), OP(k_add_u32v, 0, false), OP(k_cmp_vcc, 0, false), OP(k_cmp_sgpr, 0, false),
       OP(k_cmp_salu_cnd, 0, false), OP(k_rcp, 0, false), OP(k_sqrt, 0, false), OP(k_div_scale, 0, false),
       OP(k_div_fmas, 0, false), OP(k_div_fixup, 0, false), OP(k_mbcnt, 0, false), OP(k_lshl_add, 0, false),
+      OP(k_bfi, 0, false), OP(k_xor, 0, false), OP(k_or, 0, false), OP(k_lshlrev, 0, false), OP(k_ashrrev, 0, false), OP(k_max, 0, false),
+      OP(k_med3, 0, false), OP(k_perm, 0, false), OP(k_and_or, 0, false), OP(k_lshl_or, 0, false), OP(k_add3, 0, false), OP(k_sub_u32, 0, false),
+      OP(k_min_u32, 0, false), OP(k_fmac, 0, false), OP(k_pk_fma, 0, false), OP(k_pk_mov, 0, false),
       OP(k_mov, 0, false), OP(k_readfirstlane, 0, false), OP(k_salu, 0, false), OP(k_bcnt, 0, false), OP(k_snop, 0, false),
       OP(k_mix_v1s1, 0, false), OP(k_mix_v2s1, 0, false),
       {"k_bperm/identity", k_bperm, k_bperm_ninst, 9, true}, {"k_bperm/same-lane", k_bperm, k_bperm_ninst, 1, true},
