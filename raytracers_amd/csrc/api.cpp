@@ -565,7 +565,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
         static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
         for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
-        pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 300;
+        pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
         pol.nwaves = pl.grid_full * pl.waves;
         // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel without
         // the solo call is 1-5 % faster)

@@ -1426,58 +1426,78 @@ hipError_t launch_tile_order(int *cost, int *order, int ntiles, int tiles_x, int
 // rays then differ in length as a tile's do -- rendered irreg the same and rgbbox 1000 x 1000 5-7 % slower than the plain sort.)
 // Which pixel goes where changes the ORDER in which independent pixels are traced, nothing else.
 // ---------------------------------------------------------------------------------
-constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step -- in-order LDS atomics keep a workgroup's pixels of one bin tile by tile
+constexpr int kPxThreads = 64;        // count / place: ONE wave per workgroup, a tile per step; lane b holds bin b's count / cursor in a register
 constexpr int kPxScanThreads = 256;
 constexpr int kPxBins = 64;
-// bin = rays traced (saturating)
-__device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }
+__device__ __forceinline__ int px_bin(int rays) { return rays < kPxBins - 1 ? rays : kPxBins - 1; }   // bin = rays traced (saturating)
 
-// the workgroup's tiles [t0, t1), one after the other, one pixel per lane; f(col, lrow, rays)
+// The workgroup's tiles [t0, t1), one after the other, one pixel per lane.  For every tile and every bin that occurs in it (a handful:
+// neighbouring pixels have similar chains) f(bin, m, col, lrow) is called by the whole wave with the lane mask m of the bin's pixels
+// -- no atomics: 64 lanes adding to one LDS word serialise, and the list's order would depend on who wins.
 template <class F>
-__device__ __forceinline__ void px_for_each(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
+__device__ __forceinline__ void px_for_each_bin(const unsigned char *cost_px, const PxGeom &g, int tiles_per_block, F &&f) {
   const int ntiles = g.tiles_x * g.tiles_y;
   const int t0 = (int)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
   const int within = (int)threadIdx.x;
   for (int tile = t0; tile < t1; ++tile) {
     const int ty = tile / g.tiles_x;
     const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
-    if (col >= g.w || lrow >= g.rows_local) continue;
+    const bool in = col < g.w && lrow < g.rows_local;
     const size_t idx = (size_t)lrow * g.w + col + (size_t)(lrow >> g.rpt_log2) * (size_t)g.out_skip;
-    f(col, lrow, (int)cost_px[idx]);
+    const int bin = in ? px_bin((int)cost_px[idx]) : -1;
+    unsigned long long todo = bal(in);
+    while (todo != 0ull) {       // wave-uniform
+      const int b = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(todo));
+      const unsigned long long m = bal(bin == b);
+      f(b, m, col, lrow);
+      todo &= ~m;
+    }
   }
 }
 // counts[bin * nblocks + block]
 __global__ __launch_bounds__(kPxThreads) void px_count_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, int *counts) {
-  __shared__ int hist[kPxBins];
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  px_for_each(cost_px, g, tiles_per_block, [&](int, int, int rays) { atomicAdd(&hist[px_bin(rays)], 1); });
-  __syncthreads();
-  counts[threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+  int mine = 0;                  // lane b: the workgroup's pixels of bin b
+  px_for_each_bin(cost_px, g, tiles_per_block, [&](int b, unsigned long long m, int, int) {
+    if ((int)threadIdx.x == b) mine += (int)__popcll(m);
+  });
+  counts[threadIdx.x * nblocks + blockIdx.x] = mine;
 }
-// one workgroup: counts -> every (bin, block)'s first list position (bins in DESCENDING order of chain length); the header:
-// the model evaluated on the histogram, the classes' cuts
-__global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, int nblocks, PxPolicy pol, int *hdr) {
-  constexpr int Q = kPxScanThreads / kPxBins;        // threads per bin: each scans a quarter of the blocks
-  __shared__ int part[kPxBins][Q + 1];
-  __shared__ int bin_start[kPxBins + 1];
-  const int bin = (int)threadIdx.x / Q, q = (int)threadIdx.x % Q;
-  const int per = (nblocks + Q - 1) / Q, b0 = min(nblocks, q * per), b1 = min(nblocks, b0 + per);
-  int acc = 0;
-  for (int b = b0; b < b1; ++b) {
-    const int c = counts[bin * nblocks + b];
-    counts[bin * nblocks + b] = acc;
-    acc += c;
-  }
-  part[bin][q] = acc;
+// one workgroup per bin: its counts over the workgroups of the count pass -> exclusive prefix (in place), the bin's total
+__global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, int nblocks, int *totals) {
+  __shared__ int wsum[kPxScanThreads / 64];
+  __shared__ int carry;
+  int *const c = counts + (size_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
+  for (int base = 0; base < nblocks; base += kPxScanThreads) {
+    const int i = base + (int)threadIdx.x;
+    const int v = i < nblocks ? c[i] : 0;
+    int incl = v;                // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int k = 0; k < wave; ++k) before += wsum[k];
+    if (i < nblocks) c[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == kPxScanThreads - 1) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+// one wave: the bins' first list positions (DESCENDING chain length) -> totals[kPxBins ..), and the header: the model evaluated
+// on the histogram, the classes' cuts
+__global__ __launch_bounds__(64) void px_header_kernel(int *totals, PxPolicy pol, int *hdr) {
+  __shared__ int bin_start[kPxBins + 1];
   if (threadIdx.x == 0) {
     int a = 0;
     for (int l = kPxBins - 1; l >= 0; --l) {       // longest chains first
-      int tot = 0;
-      for (int k = 0; k < Q; ++k) { const int c = part[l][k]; part[l][k] = tot; tot += c; }
       bin_start[l] = a;
-      a += tot;
+      a += totals[l];
     }
     bin_start[kPxBins] = a;                        // all pixels
     // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
@@ -1514,28 +1534,30 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
     hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
   }
   __syncthreads();
-  for (int b = b0; b < b1; ++b) counts[bin * nblocks + b] += bin_start[bin] + part[bin][q];
+  totals[kPxBins + threadIdx.x] = bin_start[threadIdx.x];
 }
 __global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
-                                                            unsigned *list) {
-  __shared__ int cursor[kPxBins];
-  cursor[threadIdx.x] = starts[threadIdx.x * nblocks + blockIdx.x];
-  __syncthreads();
-  px_for_each(cost_px, g, tiles_per_block, [&](int col, int lrow, int rays) {
-    const int pos = atomicAdd(&cursor[px_bin(rays)], 1);
-    list[pos] = ((unsigned)lrow << 16) | (unsigned)col;
+                                                            const int *bin_start, unsigned *list) {
+  int cursor = starts[threadIdx.x * nblocks + blockIdx.x] + bin_start[threadIdx.x];   // lane b: where the workgroup's next pixel of bin b goes
+  px_for_each_bin(cost_px, g, tiles_per_block, [&](int b, unsigned long long m, int col, int lrow) {
+    const int base = __builtin_amdgcn_readlane(cursor, b);
+    if ((m >> threadIdx.x) & 1ull) list[base + lane_rank(m)] = ((unsigned)lrow << 16) | (unsigned)col;
+    if ((int)threadIdx.x == b) cursor += (int)__popcll(m);
   });
 }
 
+// `scratch`: px_scratch_ints() ints -- [bin][workgroup] counts, then the bins' totals and first positions
 hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const PxPolicy &pol, unsigned *list, int *hdr, int *scratch, hipStream_t stream) {
   const int ntiles = g.tiles_x * g.tiles_y;
   if (ntiles <= 0) return hipSuccess;
   int tpb = 16;                                     // tiles per workgroup: 1024 pixels, or more for a large frame
   while ((ntiles + tpb - 1) / tpb > kPxBlocksMax) tpb *= 2;
   const int nblocks = (ntiles + tpb - 1) / tpb;
+  int *const totals = scratch + (size_t)kPxBins * kPxBlocksMax;
   hipLaunchKernelGGL(px_count_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch);
-  hipLaunchKernelGGL(px_scan_kernel, dim3(1), dim3(kPxScanThreads), 0, stream, scratch, nblocks, pol, hdr);
-  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, list);
+  hipLaunchKernelGGL(px_scan_kernel, dim3(kPxBins), dim3(kPxScanThreads), 0, stream, scratch, nblocks, totals);
+  hipLaunchKernelGGL(px_header_kernel, dim3(1), dim3(64), 0, stream, totals, pol, hdr);
+  hipLaunchKernelGGL(px_place_kernel, dim3(nblocks), dim3(kPxThreads), 0, stream, cost_px, g, tpb, nblocks, scratch, totals + kPxBins, list);
   return hipGetLastError();
 }
 
@@ -1708,6 +1730,7 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)px_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_place_kernel);
+  (void)hipFuncGetAttributes(&a, (const void *)px_header_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)tile_place_kernel);

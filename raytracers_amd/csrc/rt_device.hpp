@@ -294,7 +294,7 @@ struct PxPolicy {
   int solo_cap;      // the one-pixel class: at most this many pixels (0: no solo loop on this launch)
 };
 constexpr int kPxBlocksMax = 2048;
-constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax; }
+constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax + 256; }
 hipError_t launch_px_order(const unsigned char *cost_px, const PxGeom &g, const PxPolicy &pol, unsigned *list, int *hdr, int *scratch, hipStream_t stream);
 hipError_t launch_place_part(const int32_t *part, int32_t *image, int w, int rows_local, int rows_per_tile, int part_id,
                              int nparts, hipStream_t stream);
