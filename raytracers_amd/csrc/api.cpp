@@ -481,6 +481,35 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         to = &ps->orders.back();
       }
       to->stamp = ++ps->order_clock;
+      if (to->sort_pending) {
+        // the view's last frame left a record: the next frames' ticket -> tile table from it (this also clears the record) ...
+        to->sort_pending = false;
+        if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
+        RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
+        to->valid = true;
+        to->have_classes = false;
+        if (int rc = request_classes(ctx, ps, to)) return rc;
+        if (to->sort_px) {
+          // ... and the view's pixel list from the per-pixel record
+          if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
+          const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, to->rec_out_skip, p.tiles_x, p.tiles_y};
+          rtk::PxPolicy pol{};
+          for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
+          // the model's bounce cadences (0.1 us; measured, profiles/r05/README.md): a scene that lives in LDS, one that is read from L2
+          const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
+          static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
+          for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
+          pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
+          pol.nwaves = pl.grid_full * pl.waves;
+          // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel
+          // without the solo call is 1-5 % faster)
+          pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+          to->px_solo = pol.solo_cap > 0;
+          RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
+                                           ctx->stream));
+          to->px_valid = true;
+        }
+      }
       // The record of a view is a deterministic function of the view, so the table is computed
       // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
       // recomputes every frame (testing aid).
@@ -549,32 +578,13 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     if (to && p.cost) {
-      // next frames' ticket -> tile table from this frame's record (also clears the record)
-      if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
-      RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
-      to->valid = true;
-      to->have_classes = false;
-      if (int rc = request_classes(ctx, ps, to)) return rc;
-      if (p.cost_px) {
-        // ... and the view's pixel list from the per-pixel record
-        if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
-        const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, p.out_skip, p.tiles_x, p.tiles_y};
-        rtk::PxPolicy pol{};
-        for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
-        // the model's bounce cadences (0.1 us; measured, profiles/r05/exp): a scene that lives in LDS, one that is read from L2
-        const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-        static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
-        for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
-        pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
-        pol.nwaves = pl.grid_full * pl.waves;
-        // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel without
-        // the solo call is 1-5 % faster)
-        pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
-        to->px_solo = pol.solo_cap > 0;
-        RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
-                                         ctx->stream));
-        to->px_valid = true;
-      }
+      // This frame recorded the view's bounce chains.  The sorts that turn the record into the view's tile order and pixel list are
+      // NOT launched here: a caller that never renders the view again (the reference's `render` keeps nothing between calls,
+      // ray.fut:246; a camera path rendered view by view) should not pay for them -- ~0.07 ms behind a 1000 x 1000 frame.  They run
+      // ahead of the view's next frame (sort_pending_record, above).
+      to->sort_pending = true;
+      to->sort_px = p.cost_px != nullptr;
+      to->rec_out_skip = p.out_skip;
     }
   }
   else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));

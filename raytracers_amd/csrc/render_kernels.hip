@@ -1439,18 +1439,29 @@ __device__ __forceinline__ void px_for_each_bin(const unsigned char *cost_px, co
   const int ntiles = g.tiles_x * g.tiles_y;
   const int t0 = (int)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
   const int within = (int)threadIdx.x;
-  for (int tile = t0; tile < t1; ++tile) {
-    const int ty = tile / g.tiles_x;
-    const int col = (tile - ty * g.tiles_x) * 8 + (within & 7), lrow = ty * 8 + (within >> 3);
-    const bool in = col < g.w && lrow < g.rows_local;
-    const size_t idx = (size_t)lrow * g.w + col + (size_t)(lrow >> g.rpt_log2) * (size_t)g.out_skip;
-    const int bin = in ? px_bin((int)cost_px[idx]) : -1;
-    unsigned long long todo = bal(in);
-    while (todo != 0ull) {       // wave-uniform
-      const int b = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(todo));
-      const unsigned long long m = bal(bin == b);
-      f(b, m, col, lrow);
-      todo &= ~m;
+  constexpr int U = 16;          // tiles whose records are loaded before the first is consumed (a dependent load per tile: ~1.5 us each)
+  for (int tb = t0; tb < t1; tb += U) {
+    int bins[U], cols[U], rows[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tile = tb + u;
+      const int ty = tile / g.tiles_x;
+      cols[u] = (tile - ty * g.tiles_x) * 8 + (within & 7);
+      rows[u] = ty * 8 + (within >> 3);
+      const bool in = tile < t1 && cols[u] < g.w && rows[u] < g.rows_local;
+      const size_t idx = (size_t)rows[u] * g.w + cols[u] + (size_t)(rows[u] >> g.rpt_log2) * (size_t)g.out_skip;
+      bins[u] = in ? (int)cost_px[idx] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int bin = bins[u] < 0 ? -1 : px_bin(bins[u]);
+      unsigned long long todo = bal(bin >= 0);
+      while (todo != 0ull) {       // wave-uniform
+        const int b = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(todo));
+        const unsigned long long m = bal(bin == b);
+        f(b, m, cols[u], rows[u]);
+        todo &= ~m;
+      }
     }
   }
 }
@@ -1489,52 +1500,54 @@ __global__ __launch_bounds__(kPxScanThreads) void px_scan_kernel(int *counts, in
   }
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
-// one wave: the bins' first list positions (DESCENDING chain length) -> totals[kPxBins ..), and the header: the model evaluated
-// on the histogram, the classes' cuts
+// one wave, lane l = bin l: the bins' first list positions (DESCENDING chain length) -> totals[kPxBins ..), and the header: the model
+// evaluated on the histogram (rt_device.hpp: PxPolicy), the classes' cuts
+__device__ __forceinline__ long long wave_sum(long long v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 __global__ __launch_bounds__(64) void px_header_kernel(int *totals, PxPolicy pol, int *hdr) {
-  __shared__ int bin_start[kPxBins + 1];
-  if (threadIdx.x == 0) {
-    int a = 0;
-    for (int l = kPxBins - 1; l >= 0; --l) {       // longest chains first
-      bin_start[l] = a;
-      a += totals[l];
+  const int l = (int)threadIdx.x;
+  const int cnt = totals[l];
+  int suf = cnt;                                   // pixels of >= l rays: inclusive suffix sum over the bins
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_down(suf, o);
+    if (l + o < 64) suf += u;
+  }
+  const int all = __builtin_amdgcn_readlane(suf, 0);
+  totals[kPxBins + l] = suf - cnt;                 // the bin's first position: the pixels of longer chains
+  auto at_least = [&](int t) { return t <= 0 ? all : (t > kPxBins - 1 ? 0 : __builtin_amdgcn_readlane(suf, t)); };   // (t: wave-uniform)
+  int thr[kPxClasses - 1] = {pol.thr[0], pol.thr[1], pol.thr[2], pol.thr[3]};
+  if (pol.thr[0] <= 0) {
+    const unsigned long long occ = bal(cnt > 0 && l >= 1);
+    const int maxlen = occ ? 63 - (int)__builtin_clzll(occ) : 1;
+    const bool solo = pol.solo_cap > 0;
+    long long T = (long long)maxlen * pol.g[solo ? 0 : 1];     // 0.1 us: the longest chain in the narrowest class there is
+    for (int it = 0; it < 4; ++it) {
+      for (int k = 0; k < kPxClasses - 1; ++k) thr[k] = (int)min((long long)kPxBins, T / pol.g[k + 1] + 1);   // class k: chains too long for class k + 1
+      if (!solo) thr[0] = kPxBins;
+      int k = kPxClasses - 1;                                  // this lane's bin: its class, its rays' share of the waves' time (0.1 us)
+      while (k > 0 && l >= thr[k - 1]) --k;
+      const long long mine = l == 0 ? 0ll : (k == kPxClasses - 1 ? (long long)cnt * l * pol.ray_ns / 100 : (long long)cnt * l * pol.g[k] / (1 << px_log2(k)));
+      const long long Tn = max(T, wave_sum(mine) / max(1, pol.nwaves));
+      if (Tn <= T) break;                                      // (uniform)
+      T = Tn;
     }
-    bin_start[kPxBins] = a;                        // all pixels
-    // class k holds the chains of >= thr[k] rays that no earlier class holds: its first position is the number of pixels
-    // with longer chains than its own longest.  (pixels of >= t rays = bin_start[t - 1] for t >= 1: the bins above t - 1)
-    auto at_least = [&](int t) { return t <= 0 ? a : (t > kPxBins - 1 ? 0 : bin_start[t - 1]); };
-    int thr[kPxClasses - 1] = {pol.thr[0], pol.thr[1], pol.thr[2], pol.thr[3]};
-    if (pol.thr[0] <= 0) {
-      // the model (rt_device.hpp: PxPolicy).  count[l] = at_least(l) - at_least(l + 1); rays of bin l: l each
-      int maxlen = 1;
-      for (int l = kPxBins - 1; l >= 1; --l)
-        if (at_least(l) > 0) { maxlen = l; break; }
-      const bool solo = pol.solo_cap > 0;
-      long long T = (long long)maxlen * pol.g[solo ? 0 : 1];     // 0.1 us: the longest chain in the narrowest class there is
-      for (int it = 0; it < 4; ++it) {
-        for (int k = 0; k < kPxClasses - 1; ++k) thr[k] = (int)min((long long)kPxBins, T / pol.g[k + 1] + 1);   // class k: chains too long for class k + 1
-        if (!solo) thr[0] = kPxBins;
-        long long busy = 0;                                     // the waves' time, 0.1 us
-        for (int l = 1; l < kPxBins; ++l) {
-          const long long n = at_least(l) - at_least(l + 1);
-          int k = kPxClasses - 1;
-          while (k > 0 && l >= thr[k - 1]) --k;
-          busy += k == kPxClasses - 1 ? n * l * pol.ray_ns / 100 : n * l * pol.g[k] / (1 << px_log2(k));
-        }
-        const long long Tn = max(T, busy / max(1, pol.nwaves));
-        if (Tn <= T) break;
-        T = Tn;
-      }
-    }
-    int t0 = pol.solo_cap > 0 ? max(thr[0], 1) : kPxBins;
-    while (t0 < kPxBins && at_least(t0) > pol.solo_cap) ++t0;   // the one-pixel class: at most solo_cap pixels
-    const int t1 = min(thr[1], t0), t2 = min(thr[2], t1), t3 = min(thr[3], t2);
-    int pos[kPxClasses + 1] = {0, at_least(t0), at_least(t1), at_least(t2), at_least(t3), a};
+  }
+  // the one-pixel class: at most solo_cap pixels (suf is non-increasing in l: the first bin that fits)
+  int t0 = kPxBins;
+  if (pol.solo_cap > 0) {
+    const unsigned long long fits = bal(suf <= pol.solo_cap && l >= max(thr[0], 1));
+    t0 = fits ? (int)__builtin_ctzll(fits) : kPxBins;
+  }
+  const int t1 = min(thr[1], t0), t2 = min(thr[2], t1), t3 = min(thr[3], t2);
+  const int p1 = at_least(t0), p2 = at_least(t1), p3 = at_least(t2), p4 = at_least(t3);
+  if (l == 0) {
+    // class k holds the chains of >= its cut that no earlier class holds: its first position is the number of pixels with longer chains
+    int pos[kPxClasses + 1] = {0, p1, p2, p3, p4, all};
     px_make_header(pos, hdr);
     hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
   }
-  __syncthreads();
-  totals[kPxBins + threadIdx.x] = bin_start[threadIdx.x];
 }
 __global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,
                                                             const int *bin_start, unsigned *list) {

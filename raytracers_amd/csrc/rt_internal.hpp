@@ -118,6 +118,8 @@ struct TileOrder {
   unsigned *px_list = nullptr;        // [px_elems] the part's pixels, longest chains first; then the header (rtk::kPxHdrInts)
   size_t cost_px_bytes = 0, px_elems = 0;
   bool px_valid = false;
+  bool sort_pending = false, sort_px = false;   // the view's last frame recorded its chains; the sorts (tile order; pixel list) run ahead of its next frame
+  int rec_out_skip = 0;               // ... KParams::out_skip of the recording frame (how cost_px is indexed)
   bool px_solo = false;               // the list was cut with a one-pixel class (the SOLO flavour of the ORD instantiation renders it)
   uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
   bool have_classes = false;   // classes[] is the host's copy of the (single) class table behind order[]
