@@ -1289,6 +1289,21 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
         p.deep_split = dp.deep_split;
         p.deep_cap_log2 = dp.cap_log2;
         if (dp.sparse && ctx->grid_div == 0) pl.grid = pl.grid_full;   // as enqueue_render launches this view
+        // ... through its pixel list when enqueue_render would (same conditions)
+        if (o.px_valid && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 && (p.nshards == 1 || p.interleave) &&
+            o.px_elems >= static_cast<size_t>(p.rows_local) * p.w && o.rows_per_tile == 8 &&
+            (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
+                                       (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {
+          p.px_list = o.px_list;
+          p.px_hdr = reinterpret_cast<const int *>(o.px_list + o.px_elems);
+          p.px_hold = ctx->px_hold;
+          p.solo = (o.px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
+          if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
+            const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
+            const int il = ns > 1 && xq == 2;
+            if (ns == 1 || il) { pl.grid = pl.grid_full; p.nshards = ns; p.interleave = il; }
+          }
+        }
       }
     nw = pl.grid * pl.waves;
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);

@@ -550,7 +550,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
-  static_assert(!ORD || (TAIL == 0 && !STATS), "ORD: no tail variant");
+  static_assert(!ORD || TAIL == 0, "ORD: no tail variant");
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1688,6 +1688,8 @@ static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
+  if (stats && p.px_hdr != nullptr && waves_per_wg == 16)   // (the instrumented launch of a view that renders through its pixel list)
+    return p.solo ? launch_pooled_t<1024, false, true, true, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, true, false, 0, true>(p, grid, stream);
   if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
