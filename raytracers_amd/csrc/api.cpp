@@ -556,6 +556,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.px_list = to->px_list;
       p.px_hdr = reinterpret_cast<const int *>(to->px_list + to->px_elems);
       p.px_hold = ctx->px_hold;
+      p.px_prio = ctx->px_prio;
       p.cold = 0;
       p.solo = (to->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
       if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
@@ -792,6 +793,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_max_tiles = std::max(0, v);
   } else if (k == "px_ray_ns") {
     ctx->px_ray_ns = std::max(0, std::min(100000, v));
+  } else if (k == "px_prio") {
+    ctx->px_prio = std::max(0, std::min(3, v));
   } else if (k == "px_hold") {
     ctx->px_hold = v & 0x1f;
   } else if (k == "px_solo_div") {
@@ -1297,6 +1300,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           p.px_list = o.px_list;
           p.px_hdr = reinterpret_cast<const int *>(o.px_list + o.px_elems);
           p.px_hold = ctx->px_hold;
+          p.px_prio = ctx->px_prio;
           p.solo = (o.px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
           if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
             const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;

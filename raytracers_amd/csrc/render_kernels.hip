@@ -814,6 +814,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               }, &sp);
               if (!got) {
                 exhausted = true;
+                if (STATS) tr_exh = wall_clock64();
                 break;
               }
               q_next = sp.q_next;
@@ -825,7 +826,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               q_enter = false;
               if ((p.px_hold >> q_cls) & 1) {
                 hold = true;
-                __builtin_amdgcn_s_setprio(3);
+                // (the issue priority of a wave that holds a ticket: s_setprio takes an immediate)
+                if (p.px_prio >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (p.px_prio == 2) __builtin_amdgcn_s_setprio(2);
+                else if (p.px_prio == 1) __builtin_amdgcn_s_setprio(1);
               }
               // the ticket's list entries, one per lane, in ONE coalesced load: the refills that consume the ticket take
               // theirs from the lane that holds it (ds_bpermute) instead of a dependent global load each
@@ -842,7 +846,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               slot = lrow * p.w + col + k * p.out_skip;
               ptile = (lrow >> 3) * p.tiles_x + (col >> 3);
               const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
-              primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
+              // (u, v by their divisions, not from the tables: the same bits -- the tables hold pixel_u / pixel_v -- and two dependent
+              // global loads fewer in a refill whose rays, all of one length, have nothing else in flight to hide them)
+              primary_dir_uv(p.cam, pixel_u(col, p.w), pixel_v(grow, p.h), r);
               want = false;
             }
             q_next += (cnt < avail) ? cnt : avail;

@@ -242,6 +242,7 @@ struct KParams {
   const int *px_hdr;     // pixel tickets (the ORD instantiation; nullptr: tile tickets): header of the view's pixel list (kPxHdrInts) ...
   const unsigned *px_list;   // ... and the list itself: (local row << 16) | column, longest bounce chains first
   int px_hold;           // bit k: a wave that draws a ticket of class k does not refill until it is finished
+  int px_prio;           // ... and runs at this issue priority meanwhile (0 .. 3)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
 };
