@@ -846,9 +846,9 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
               slot = lrow * p.w + col + k * p.out_skip;
               ptile = (lrow >> 3) * p.tiles_x + (col >> 3);
               const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
-              // (u, v by their divisions, not from the tables: the same bits -- the tables hold pixel_u / pixel_v -- and two dependent
-              // global loads fewer in a refill whose rays, all of one length, have nothing else in flight to hide them)
-              primary_dir_uv(p.cam, pixel_u(col, p.w), pixel_v(grow, p.h), r);
+              // (u, v from the tables, as the tile tickets take them; computing them here -- two IEEE divisions instead of two dependent
+              // loads -- measured 0 .. +4 % SLOWER: a refill is bound by its VALU work, profiles/r05/exp/e9)
+              primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], r);
               want = false;
             }
             q_next += (cnt < avail) ? cnt : avail;
