@@ -54,7 +54,7 @@ struct rt_context {
   int pixel_order = 1;      // pooled family: an ordered single frame draws its tickets from the view's PIXEL list (rt_device.hpp: pixel tickets; the ORD instantiation). 0 = tile tickets only; 1 = where measured faster (api.cpp); 2 = whenever the view has a list (testing)
   int px_thr[4] = {0, 24, 14, 9};    // ... the list's classes: [0] == 0 (default): cut by the model of rt_device.hpp (PxPolicy) from the view's histogram; else chains of >= px_thr[0] rays go out one pixel per ticket (solo loop), >= [1] 8 per ticket, >= [2] 16, >= [3] 32, the rest 64
   int px_g[5] = {0, 0, 0, 0, 0};     // ... the model's bounce cadences for 1 / 8 / 16 / 32 / 64 rays per wave, 0.1 us (0: the built-in figures, by where the scene lives)
-  int px_max_tiles = 65536; // ... pixel_order = 1: launches of more tiles than this keep the tile tickets (a work-bound frame gains nothing from the list)
+  int px_max_tiles = 40000; // ... pixel_order = 1: launches of more tiles than this keep the tile tickets (a work-bound frame gains nothing from the list)
   int px_ray_ns = 0;        // ... and a wave's time per ray of the 64-pixel class, ns (0: 250)
   int px_hold = 0xf;        // ... bit k: a wave holding a ticket of class k does not refill (classes 0 .. 3: 1, 8, 16, 32 pixels)
   int px_prio = 3;          // ... at this issue priority (s_setprio 0 .. 3)

@@ -227,6 +227,84 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
     c.close()
 
 
+@pytest.mark.parametrize("opts", [dict(pixel_order=2), dict(pixel_order=1), dict(pixel_order=0),
+                                  dict(pixel_order=2, px_solo=1, px_w8=1, px_w16=1, px_w32=1),          # every pixel a one-pixel ticket (capped: then 8s)
+                                  dict(pixel_order=2, px_solo=255, px_w8=255, px_w16=255, px_w32=255),  # no classes: the plain sorted list
+                                  dict(pixel_order=2, px_solo=4, px_w8=3, px_w16=2, px_w32=2, px_hold=0, px_prio=0),
+                                  dict(pixel_order=2, px_solo=255, px_w8=2, px_w16=2, px_w32=1, px_hold=31, xcd_queues=0, static_first=0),
+                                  dict(pixel_order=2, solo=0), dict(pixel_order=2, grid_div=16, px_solo_div=1),
+                                  dict(pixel_order=2, px_g1=1, px_g8=2, px_g16=3, px_g32=4, px_g64=5, px_ray_ns=1),
+                                  dict(pixel_order=2, px_g1=1000, px_g64=20000, px_ray_ns=20000, thr_shade=8),
+                                  dict(pixel_order=2, gpu_build=0, treelet=4), dict(pixel_order=2, xcd_queues=1)])
+def test_pixel_tickets(R, opts):
+    """Ordered single frames that draw their tickets from the view's PIXEL LIST (the first frame records every pixel's
+    chain length, the sorts run ahead of the second frame, the ORD instantiation renders from it): the list's classes cut by the device's
+    model, by hand at both extremes, with and without holding / the solo loop / static first tickets, on one counter, with strips (no list:
+    the tile tickets), by the host builder with another treelet cut (no solo loop).  Frames 1 .. 4 of a view into a poisoned buffer, a part
+    of three packed and then IN PLACE (the same view: the list recorded by the packed frame serves the in-place one), a view first recorded
+    by a BATCH (no per-pixel record: its first single frame records again), and the batch entry after the list exists.  Pixels: the oracle's."""
+    import torch
+    from raytracers_amd.dist import tile_rows
+    c = R.Context()
+    c.set_variant(3)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    for name, custom, h, w in _solo_cases()[:5] + [("rgbbox", None, 8, 8), ("irreg", None, 1, 77)]:
+        if custom is None:
+            orc, sc = _oracle(name), _scene(c, name)
+        else:
+            orc = O.OracleScene("custom", spheres7=custom[0], look_from=custom[1], look_at=custom[2], fov=custom[3])
+            sc = c.scene_from_spheres(*custom)
+        want, _ = orc.render(h, w)
+        ps = R.prepare_scene(h, w, sc)
+        out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        for frame in range(4):
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(out.data_ptr(), h, w, ps)
+            c.sync()
+            assert int((out.cpu().numpy() != want).sum()) == 0, (name, frame)
+        rows = R.part_rows(h, 1, 3)
+        if rows:
+            part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
+            for frame in range(3):
+                part.fill_(-3)
+                torch.cuda.synchronize()
+                R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
+                c.sync()
+                assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, "part", frame)
+            image = torch.full((h, w), -5, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for frame in range(2):
+                R.render_inplace_into(image.data_ptr(), h, w, ps, part=1, nparts=3)
+            c.sync()
+            got = image.cpu().numpy()
+            mine = np.zeros(h, bool)
+            mine[tile_rows(h, 1, 3)] = True
+            assert int((got[mine] != want[mine]).sum()) == 0 and bool((got[~mine] == -5).all()), (name, "in place")
+        ps.free()
+        # a view whose tiles a batch recorded first
+        ps = R.prepare_scene(h, w, sc)
+        buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+        c.sync()
+        assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch first")
+        for frame in range(3):
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(out.data_ptr(), h, w, ps)
+            c.sync()
+            assert int((out.cpu().numpy() != want).sum()) == 0, (name, "after a batch", frame)
+        buf.fill_(-7)
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+        c.sync()
+        assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch after the list")
+        ps.free()
+    c.close()
+
+
 @pytest.mark.parametrize("opts", [dict(), dict(handover=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
                                   dict(xcd_queues=0, thr_shade=64), dict(handover=2, donate_max=1), dict(handover=2, donate_max=64),
                                   dict(handover=2, donate_max=8, thr_shade=8), dict(handover=2, donate_max=64, grid_div=4)])
