@@ -1301,7 +1301,9 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           p.px_hdr = reinterpret_cast<const int *>(o.px_list + o.px_elems);
           p.px_hold = ctx->px_hold;
           p.px_prio = ctx->px_prio;
-          p.solo = (o.px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
+          // (the instrumented launch walks a list's one-pixel tickets in the pooled loop, as tickets of one held pixel: solo_trace keeps
+          // no counters, and the trace's item counts are checked against the oracle's)
+          p.solo = 0;
           if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
             const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
             const int il = ns > 1 && xq == 2;
