@@ -438,7 +438,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         // tiles hold this frame's longest chains is as chaotic as the chains themselves, profiles/r03/exp/e25.)
         TileOrder o{};
         // (pixel tickets: the per-pixel record and the pixel list of the view, if this context may use them)
-        const bool px_ok = ctx->pixel_order != 0 && w < 65536 && p.rows_local < 65536;
+        const bool px_ok = ctx->pixel_order != 0 && w < 65536 && p.rows_local < 65536 && (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
         const size_t px_bytes = px_ok ? static_cast<size_t>(h) * static_cast<size_t>(w) : 0;
         const size_t px_elems = px_ok ? static_cast<size_t>(p.rows_local) * static_cast<size_t>(p.w) : 0;
         if (ps->orders.size() >= 8) {
