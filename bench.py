@@ -21,6 +21,9 @@ protocol: one launch per frame, up to --frames-in-flight steps overlapped on sep
 (futhark/main.c:107-124) -- is reported next to it as `serial_value` / `serial_ms_per_frame`, and the
 >= 10x-MI100 target check (`targets`) is quoted on the serial figures.
 
+The K-step bracket is timed --repeats times (default 5; each behind its own warm-up passes and poison fill, each verified): steps /
+ms_per_step / value describe the MEDIAN bracket, brackets_ms / value_min / value_max the rest (--repeats 1: one bracket, no such keys).
+
 Every timed launch is VERIFIED: the framebuffers are poisoned before the timed region and,
 after its closing fence, the images of every lane are checksummed on the device
 (c = c * 31 + pixel) and compared with the oracle's checksums.  A mismatch fails
@@ -670,14 +673,15 @@ def main():
             ps3.free()
             ps2.free()
         cold = {"first_frames_ms": first,
-                "first_frames_note": "frames 1..4 of a fresh prepared scene (kernel time, events): frame 1 has no tile order (it records "
-                                     "one), from frame 2 on the view's order / deep-tile policy / solo pixels apply",
+                "first_frames_note": "frames 1..4 of a fresh prepared scene (kernel time, events): frame 1 has no order (it records every pixel's "
+                                     "bounce-chain length), frame 2 first sorts that record (the view's tile order and pixel list: ~0.07 ms) and "
+                                     "renders through it, frames 3.. are the warm figure",
                 "camera_path_ms_per_frame": path,
                 "camera_path_note": "20 frames, a camera per frame, ONE rt_render_batch launch (no per-view order); first and last "
                                     "frame checked against single renders of the same cameras",
                 "camera_path_frame_by_frame_ms": path_serial,
                 "camera_path_frame_by_frame_note": "the same 20 cameras one render at a time on a fresh prepared scene: every view is new "
-                                                   "(no tile order, no solo pixels; the frame also records its tile costs)"}
+                                                   "(no order, no solo pixels; the frame records its chains, nothing sorts them: no view is rendered twice)"}
 
     # N > 1: the configuration north_star states its scaling target on (irreg 4000x4000), one frame at a time
     scale_extra = None
@@ -837,8 +841,9 @@ def main():
                 if all(f"{sc}_{w}x{h}" in ff for sc, h, w in frames):
                     out["serial_cold_value"] = rays_step / sum(ff[f"{sc}_{w}x{h}"][0] for sc, h, w in frames) / 1e3
                     out["serial"]["cold_value"] = out["serial_cold_value"]
-                    out["serial"]["cold_value_note"] = ("Mray/s with every frame the first of its view (no tile order, no deep-tile policy, no solo "
-                                                        "pixels; the frame also records its tile costs and sorts them): first_frames_ms[0] of each scene")
+                    out["serial"]["cold_value_note"] = ("Mray/s with every frame the first of its view (no order, no deep-tile policy, no solo pixels; the "
+                                                        "frame records its chains -- the sorts run ahead of the view's next frame, if there is one): "
+                                                        "first_frames_ms[0] of each scene")
             if tg:
                 out["targets"] = {"note": ">= 10x the published MI100 Futhark render times (README.md:50), one frame at a time: `ms` a view "
                                           "rendered before (warm), `cold_ms` a view never seen (the reference's render is stateless)", **tg}
