@@ -1302,7 +1302,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           p.px_hold = ctx->px_hold;
           p.px_prio = ctx->px_prio;
           // (the instrumented launch walks a list's one-pixel tickets in the pooled loop, as tickets of one held pixel: solo_trace keeps
-          // no counters, and the trace's item counts are checked against the oracle's)
+          // no counters, and the trace's item counts are meant to be the frame's complete work)
           p.solo = 0;
           if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
             const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
