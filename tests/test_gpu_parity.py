@@ -1383,6 +1383,10 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["verified"] is True and d["gather_mode"].startswith("direct-store"), d["gather_mode"]
     assert d["irreg_4000"]["verified"] is True
+    # ... the irreg 4000 x 4000 record through BOTH exchanges in the one run (each verified), the prediction of tools/scale_prediction.py next to them
+    assert set(d["irreg_4000"]["by_exchange"]) == {"direct", "gather"} and d["irreg_4000"]["exchange"] == "direct"
+    assert all(r["ms_per_frame"] > 0 and r["batch"]["ms_per_frame"] > 0 for r in d["irreg_4000"]["by_exchange"].values())
+    assert d["irreg_4000"]["predicted"]["source"].startswith("profiles/r") and "irreg_4000_one_frame_direct" in d["irreg_4000"]["predicted"]
 
 
 def test_bench_refuses_more_gpus_than_there_are():
