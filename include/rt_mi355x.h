@@ -67,6 +67,11 @@ const char *rt_context_gather_mode(rt_context *ctx);        /* "none", "direct-s
 int rt_context_rccl_ranks(rt_context *ctx);                 /* ranks of the RCCL communicator behind the gather (0: RCCL is not what carries it) */
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
+/* What the last render entry of this context enqueued, for benches and profiles that want to assert which kernel ran (pixels never
+ * depend on it): "family=pooled tickets=pixel-list|tiles-ordered|tiles-raster instantiation=ORD|ORD+SOLO|SOLO|COLD|DONATE|plain frames=..
+ * tiles=.. grid=.. waves=.. counters=.. deep_class=.. deep_split=.. recording=0|1|2".  Owned by ctx; "" before the first render.
+ * (A multi-device context: the first device's part.) */
+const char *rt_context_last_launch(const rt_context *ctx);
 int rt_context_sync(rt_context *ctx);
 int rt_context_set_variant(rt_context *ctx, int variant);
 /* Tuning knobs by name (see DESIGN.md "knobs"); unknown name -> error. */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, LIB_NAME)
 # every symbol include/rt_mi355x.h declares
 RT_SYMBOLS = [
     "rt_context_create", "rt_device_count", "rt_context_create_multi", "rt_context_num_devices", "rt_context_gather_mode", "rt_context_rccl_ranks",
-    "rt_context_destroy", "rt_last_error", "rt_context_sync", "rt_context_set_variant",
+    "rt_context_destroy", "rt_last_error", "rt_context_last_launch", "rt_context_sync", "rt_context_set_variant",
     "rt_context_set_option", "rt_context_device_info",
     "rt_scene_rgbbox", "rt_scene_irreg", "rt_scene_floor", "rt_scene_from_spheres", "rt_scene_num_spheres",
     "rt_scene_free",
@@ -59,6 +59,7 @@ def _load():
         "rt_context_rccl_ranks": (C.c_int, [vp]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, [vp]),
+        "rt_context_last_launch": (C.c_char_p, [vp]),
         "rt_context_sync": (C.c_int, [vp]),
         "rt_context_set_variant": (C.c_int, [vp, C.c_int]),
         "rt_context_set_option": (C.c_int, [vp, C.c_char_p, i64]),

@@ -72,6 +72,11 @@ class Context:
         return lib.rt_context_gather_mode(self._h).decode()
 
     @property
+    def last_launch(self):
+        """what the last render entry enqueued: family, tickets (pixel list / ordered tiles / raster), instantiation, launch shape"""
+        return lib.rt_context_last_launch(self._h).decode()
+
+    @property
     def rccl_ranks(self):
         """ranks of the RCCL communicator behind a multi-device context's gather (0: RCCL is not what carries it)"""
         return int(lib.rt_context_rccl_ranks(self._h))

@@ -381,6 +381,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   }
   if (pl.variant == RT_VARIANT_PIXEL) {
     RT_HIP(ctx, rtk::launch_pixel(p, stats, ctx->stream));
+    ctx->last_launch = stats ? "family=pixel (instrumented)" : "family=pixel";
     return 0;
   }
   p.nframes = nframes;
@@ -578,6 +579,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.donate = ctx->handover == 2 ? ctx->donate_max : 64;
     }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+    {
+      // (which instantiation launch_pooled picks, in its own order of precedence)
+      const bool single_px = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == rtk::kTreeletDepth;
+      const char *inst = p.px_hdr ? (p.solo ? "ORD+SOLO" : "ORD") : (p.cold && pl.waves == 16) ? (single_px ? "COLD+SOLO" : "COLD")
+                         : (p.donate && pl.waves == 16) ? (single_px ? "DONATE+SOLO" : "DONATE") : (single_px ? "SOLO" : "plain");
+      char buf[256];
+      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s instantiation=%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
+                    p.px_hdr ? "pixel-list" : (p.order ? "tiles-ordered" : "tiles-raster"), inst, p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
+                    p.interleave ? "(turns)" : "", p.px_hdr ? 0 : p.deep_class, p.px_hdr ? 0 : p.deep_split, p.cost ? (p.cost_px ? 2 : 1) : 0);
+      ctx->last_launch = buf;
+    }
     if (to && p.cost) {
       // This frame recorded the view's bounce chains.  The sorts that turn the record into the view's tile order and pixel list are
       // NOT launched here: a caller that never renders the view again (the reference's `render` keeps nothing between calls,
@@ -588,7 +600,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       to->rec_out_skip = p.out_skip;
     }
   }
-  else RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
+  else {
+    RT_HIP(ctx, rtk::launch_persistent(p, false, pl.grid, pl.waves, ctx->stream));
+    ctx->last_launch = "family=persistent";
+  }
   return 0;
 }
 using rti::enqueue_render;
@@ -683,6 +698,7 @@ extern "C" int rt_device_count(void) {
 }
 
 extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char *rt_context_last_launch(const rt_context *ctx) { return ctx ? ctx->last_launch.c_str() : ""; }
 
 extern "C" int rt_context_sync(rt_context *ctx) {
   if (!ctx) return 1;

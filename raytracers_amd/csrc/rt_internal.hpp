@@ -21,6 +21,7 @@ struct rt_context {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  std::string last_launch;  // what the last render entry enqueued (rt_context_last_launch): family, tickets, instantiation, launch shape
   int num_cu = 0;
   int lds_bytes = 0;
   std::string name;

@@ -264,6 +264,12 @@ def test_pixel_tickets(R, opts):
             R.render_into(out.data_ptr(), h, w, ps)
             c.sync()
             assert int((out.cpu().numpy() != want).sum()) == 0, (name, frame)
+        if name in ("rgbbox", "irreg") and h * w > 64 and "xcd_queues" not in opts:
+            # (which kernel rendered the view's fourth frame: rt_context_last_launch)
+            if opts.get("pixel_order") == 2:
+                assert "tickets=pixel-list" in c.last_launch and "instantiation=ORD" in c.last_launch, c.last_launch
+            elif opts.get("pixel_order") == 0:
+                assert "tickets=tiles-ordered" in c.last_launch, c.last_launch
         rows = R.part_rows(h, 1, 3)
         if rows:
             part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
