@@ -616,6 +616,7 @@ def main():
         nser = max(10, args.steps // 2)
         serial = timed(nser, 0)
         n_verified += verify([serial_lane], "serial region,")
+        serial_launch = {f"{sc}_{w}x{h}": pr.ctx.last_launch for (sc, h, w), pr in zip(frames, serial_lane.prs)}   # which kernel rendered them
 
     # The FIRST frames of a view (the reference's `render` is stateless, ray.fut:246; here the tile order, the deep-tile
     # policy and the solo pixels exist from a view's second frame on) and a camera path (a batch with a camera per frame
@@ -818,7 +819,7 @@ def main():
             out["serial"] = {
                 "note": "the reference's protocol: one frame at a time on one stream (futhark/main.c:107-124), library-default "
                         "knobs, measured right after the timed region; kernel_ms = HIP events around each launch",
-                "launch": {f"{sc}_{w}x{h}": serial_lane.prs[i].ctx.last_launch for i, (sc, h, w) in enumerate(frames)},
+                "launch": serial_launch,
                 "value": out["serial_value"], "ms_per_step": sdt / nser * 1e3, "kernel_ms": out["serial_ms_per_frame"],
                 "alg_bytes_GBs": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
                                   / (skms[i] * 1e-3) / 1e9 for i, (sc, h, w) in enumerate(frames)}}
