@@ -52,6 +52,7 @@ struct rt_context {
   int xcd_queues = -1;      // pooled family: the tile queue's ticket counters (rt_device.hpp). -1 (auto) = 2: eight counters, one per XCD, taking turns over ONE queue, for every frame and batch; 1: a strip of tile columns per counter (single frames only); 0: one counter
   int tpt_log2 = -1;        // pooled family: log2 of the tiles a ticket covers. -1 (auto): 0 for a single frame; a batch 2, 1 or 0 by the tiles a wave gets (>= 48, >= 24, fewer)
   int static_first = 1;     // pooled family: a wave's first ticket is its own number (no atomic)
+  int first_order = 1;      // pooled family: a view's first single frame (no record yet) visits the tile rows, and blocks of 8 tiles inside a row, in bit-reversed order instead of top to bottom, left to right (0: raster)
   int pixel_order = 1;      // pooled family: an ordered single frame draws its tickets from the view's PIXEL list (rt_device.hpp: pixel tickets; the ORD instantiation). 0 = tile tickets only; 1 = where measured faster (api.cpp); 2 = whenever the view has a list (testing)
   int px_thr[4] = {0, 24, 14, 9};    // ... the list's classes: [0] == 0 (default): cut by the model of rt_device.hpp (PxPolicy) from the view's histogram; else chains of >= px_thr[0] rays go out one pixel per ticket (solo loop), >= [1] 8 per ticket, >= [2] 16, >= [3] 32, the rest 64
   int px_g[5] = {0, 0, 0, 0, 0};     // ... the model's bounce cadences for 1 / 8 / 16 / 32 / 64 rays per wave, 0.1 us (0: the built-in figures, by where the scene lives)
@@ -72,6 +73,12 @@ struct rt_context {
     float *u, *v;
   };
   std::vector<UvTable> uv;
+  // per-(tile grid) visiting order of a view's FIRST frame (first_order = 1): tile rows, and blocks of 8 tiles inside a row, in bit-reversed order
+  struct FirstOrder {
+    int tiles_x, tiles_y;
+    int *order;   // [rtk::order_table_ints(tiles_x * tiles_y)] a permutation of the tiles, then zeroed class tables
+  };
+  std::vector<FirstOrder> first_orders;
   // Freed device blocks kept for the next prepare_scene (the reference's harness prepares the same
   // scene `runs` times: hipMalloc / hipFree of a few MB cost more than the build itself).
   struct Block {

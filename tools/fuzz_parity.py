@@ -70,6 +70,7 @@ while time.time() < t_end:
                  handover=int(rng.choice([0, 1, 1, 2, 2])), donate_max=int(rng.choice([1, 4, 64])), look_max=int(rng.choice([0, 0, 1, 16, 32, 64])),
                  # pixel tickets (ordered single frames draw from the view's pixel list): off / where the library would / always;
                  # the chain lengths at which the list's classes (1, 8, 16, 32, 64 pixels per ticket) are cut, which classes hold their wave
+                 first_order=int(rng.integers(0, 2)),     # a view's first frame: tile rows top to bottom / in bit-reversed order
                  pixel_order=int(rng.choice([0, 1, 2, 2, 2])), px_solo=int(rng.choice([0, 0, 0, 1, 2, 4, 24, 255])), px_w8=int(rng.choice([1, 3, 24, 255])),
                  px_w16=int(rng.choice([1, 2, 5, 14])), px_w32=int(rng.choice([1, 2, 3, 9])), px_hold=int(rng.integers(0, 32)),
                  px_solo_div=int(rng.choice([1, 4, 64, 4096])),
