@@ -544,6 +544,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           // without the solo call is 1-5 % faster)
           pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
           to->px_solo = pol.solo_cap > 0;
+          pol.zip = ctx->px_zip;
           RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
                                            ctx->stream));
           to->px_valid = true;
@@ -857,6 +858,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_max_tiles = std::max(0, v);
   } else if (k == "px_ray_ns") {
     ctx->px_ray_ns = std::max(0, std::min(100000, v));
+  } else if (k == "px_zip") {
+    ctx->px_zip = v != 0;
   } else if (k == "px_prio") {
     ctx->px_prio = std::max(0, std::min(3, v));
   } else if (k == "px_hold") {

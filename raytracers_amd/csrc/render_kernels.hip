@@ -1553,6 +1553,7 @@ __global__ __launch_bounds__(64) void px_header_kernel(int *totals, PxPolicy pol
     int pos[kPxClasses + 1] = {0, p1, p2, p3, p4, all};
     px_make_header(pos, hdr);
     hdr[6] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);          // (for diagnostics: the cuts that were used)
+    hdr[7] = pol.zip;
   }
 }
 __global__ __launch_bounds__(kPxThreads) void px_place_kernel(const unsigned char *cost_px, PxGeom g, int tiles_per_block, int nblocks, const int *starts,

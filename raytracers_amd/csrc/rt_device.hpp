@@ -65,8 +65,9 @@ struct TicketSpan { unsigned q_next, q_end; unsigned cls; };   // cls: pixel tic
 // kPxClasses segments by chain length.  A ticket of class k covers 1 << kPxLog2[k] consecutive pixels of the list: the longest
 // chains go out one pixel per ticket (traced by the solo loop), the next ones 8 / 16 / 32 per ticket to waves that do not refill
 // while they trace them (a wave's bounce cadence grows with the rays it carries: ~8 us per bounce with 16 rays, ~17 with 40), the
-// bulk 64 per ticket.  The table's header (kPxHdrInts ints, device memory, written by px_scan_kernel):
+// bulk 64 per ticket.  The table's header (kPxHdrInts ints, device memory, written by px_header_kernel):
 //   [0 .. 5] first list position of class k (k = 5: the number of pixels)   [8 .. 13] first ticket of class k (k = 5: all tickets)
+//   [6] the cuts that were used (diagnostics)   [7] != 0: the bulk's tickets are zipped
 constexpr int kPxClasses = 5;
 constexpr int kPxHdrInts = 16;
 __host__ __device__ inline int px_log2(int cls) { return cls == 0 ? 0 : cls + 2; }   // 1, 8, 16, 32, 64 pixels
@@ -75,7 +76,17 @@ __host__ __device__ inline TicketSpan px_ticket_span(unsigned t, const int *hdr)
   while (k + 1 < kPxClasses && t >= (unsigned)hdr[8 + k + 1]) ++k;
   TicketSpan sp;
   sp.cls = (unsigned)k;
-  sp.q_next = (unsigned)hdr[k] + ((t - (unsigned)hdr[8 + k]) << px_log2(k));
+  unsigned j = t - (unsigned)hdr[8 + k];
+  if (k == kPxClasses - 1 && hdr[7] != 0) {
+    // the bulk ZIPPED (hdr[7], the default): its tickets alternately from the long end and from the short end of the segment.  Sorted
+    // straight through, the list ends in one- and two-ray pixels -- nothing but SHADE operations, 60 of whose 250 instructions are
+    // division and square-root expansions, on every wave of the chip at once; zipped, that work runs next to the box tests of the
+    // longer bulk chains all the way, and the queue ends in the middle of the bulk (chains of ~3 rays: a short drain).  irreg 1000 x 1000
+    // 0.274 -> 0.249 ms, 700 x 700 -7.5 %, rgbbox 500 x 500 -7 %, 1000 x 1000 +-0 (profiles/r05/exp/e13)
+    const unsigned n = (unsigned)hdr[8 + k + 1] - (unsigned)hdr[8 + k];
+    j = (j & 1u) ? n - 1u - (j >> 1) : (j >> 1);
+  }
+  sp.q_next = (unsigned)hdr[k] + (j << px_log2(k));
   const unsigned end = sp.q_next + (1u << px_log2(k)), seg_end = (unsigned)hdr[k + 1];
   sp.q_end = end < seg_end ? end : seg_end;
   return sp;
@@ -293,6 +304,7 @@ struct PxPolicy {
   int ray_ns;        // a wave's time per ray in the 64-pixel class (rays of mixed phases share the wave: cheaper than g[4] / 64, the lockstep figure)
   int nwaves;
   int solo_cap;      // the one-pixel class: at most this many pixels (0: no solo loop on this launch)
+  int zip;           // the bulk's tickets alternately from both ends of its segment (px_ticket_span)
 };
 constexpr int kPxBlocksMax = 2048;
 constexpr size_t px_scratch_ints() { return (size_t)64 * kPxBlocksMax + 256; }

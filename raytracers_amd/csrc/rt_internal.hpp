@@ -59,6 +59,7 @@ struct rt_context {
   int px_max_tiles = 40000; // ... pixel_order = 1: launches of more tiles than this keep the tile tickets (a work-bound frame gains nothing from the list)
   int px_ray_ns = 0;        // ... and a wave's time per ray of the 64-pixel class, ns (0: 250)
   int px_hold = 0xf;        // ... bit k: a wave holding a ticket of class k does not refill (classes 0 .. 3: 1, 8, 16, 32 pixels)
+  int px_zip = 1;           // ... the bulk's tickets alternately from the long and from the short end of its segment (0: sorted straight through)
   int px_prio = 3;          // ... at this issue priority (s_setprio 0 .. 3)
   int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last

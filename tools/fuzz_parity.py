@@ -72,7 +72,7 @@ while time.time() < t_end:
                  # the chain lengths at which the list's classes (1, 8, 16, 32, 64 pixels per ticket) are cut, which classes hold their wave
                  first_order=int(rng.integers(0, 2)),     # a view's first frame: tile rows top to bottom / in bit-reversed order
                  pixel_order=int(rng.choice([0, 1, 2, 2, 2])), px_solo=int(rng.choice([0, 0, 0, 1, 2, 4, 24, 255])), px_w8=int(rng.choice([1, 3, 24, 255])),
-                 px_w16=int(rng.choice([1, 2, 5, 14])), px_w32=int(rng.choice([1, 2, 3, 9])), px_hold=int(rng.integers(0, 32)),
+                 px_w16=int(rng.choice([1, 2, 5, 14])), px_w32=int(rng.choice([1, 2, 3, 9])), px_hold=int(rng.integers(0, 32)), px_zip=int(rng.integers(0, 2)),
                  px_solo_div=int(rng.choice([1, 4, 64, 4096])),
                  # ... and the constants of the model that cuts the classes when px_solo is 0 (bounce cadences in 0.1 us, ns per ray)
                  px_g1=int(rng.choice([0, 1, 25, 1000])), px_g8=int(rng.choice([0, 3, 45])), px_g16=int(rng.choice([0, 5, 65])),

@@ -8,8 +8,8 @@ timeout 150 python tools/cold_probe.py 1000 "pixel_order=0" "pixel_order=1" 2>&1
 timeout 150 python tools/cold_probe.py 500 "pixel_order=0" "pixel_order=1" 2>&1 | grep -v amdgpu > $OUT/cold_probe_500.txt
 timeout 400 python tools/scale_prediction.py 20 > $OUT/scale_prediction.json 2> $OUT/scale_prediction.err
 tail -n4 $OUT/scale_prediction.err
-timeout 170 python tools/fuzz_parity.py 150 40101 > $OUT/fuzz_small_final.txt 2>&1; tail -n1 $OUT/fuzz_small_final.txt
-timeout 170 python tools/fuzz_parity.py 150 40201 700 300000 > $OUT/fuzz_large_final.txt 2>&1; tail -n1 $OUT/fuzz_large_final.txt
+timeout 100 python tools/fuzz_parity.py 80 90101 > $OUT/fuzz_small_final.txt 2>&1; tail -n1 $OUT/fuzz_small_final.txt
+timeout 100 python tools/fuzz_parity.py 80 90201 700 300000 > $OUT/fuzz_large_final.txt 2>&1; tail -n1 $OUT/fuzz_large_final.txt
 export AB_TIMEOUT=60
 {
 for s in rgbbox irreg; do for n in 200 300 500 700 1000 1400 2000; do

@@ -136,6 +136,7 @@ static int run_px(std::mt19937 &rng, bool verbose) {
   for (int k = 1; k < kPxClasses; ++k) if (pos[k] < pos[k - 1]) pos[k] = pos[k - 1];
   int hdr[kPxHdrInts];
   px_make_header(pos, hdr);
+  hdr[7] = static_cast<int>(rng() & 1);      // the bulk zipped or not
   QueueConst qc{};
   qc.ns_log2 = (rng() & 1) ? 3 : 0;
   qc.interleave = qc.ns_log2 == 3;
