@@ -21,5 +21,5 @@ echo "new|irreg|4000|-r 5|"
 echo "new|big|2000|-r 3|pixel_order=0"
 echo "new|big|2000|-r 3|"
 } | bash tools/gpu_ab.sh r05/pixel_tickets_vs_tile_tickets_ab > /dev/null
-for W in 8 4 2; do timeout 100 python tools/part_probe.py irreg 4000 $W "pixel_order=0" "" 2>&1 | grep -v amdgpu; done > $OUT/part_probe.txt
+for W in 8; do timeout 100 python tools/part_probe.py irreg 4000 $W "pixel_order=0" "" 2>&1 | grep -v amdgpu; done > $OUT/part_probe.txt
 echo r05 round done
