@@ -130,26 +130,11 @@ int get_uv(rt_context *ctx, int64_t w, int64_t h, const float **u, const float *
 int get_first_order(rt_context *ctx, int tiles_x, int tiles_y, const int **out) {
   for (const auto &t : ctx->first_orders)
     if (t.tiles_x == tiles_x && t.tiles_y == tiles_y) { *out = t.order; return 0; }
-  const int ntiles = tiles_x * tiles_y;
-  std::vector<int> h(static_cast<size_t>(rtk::order_table_ints(ntiles)), 0);
-  auto bitrev = [](int i, int bits) { int r = 0; for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b); return r; };
-  const int nb = (tiles_x + 7) / 8;
-  int by = 0, bx = 0;
-  while ((1 << by) < tiles_y) ++by;
-  while ((1 << bx) < nb) ++bx;
-  int k = 0;
-  for (int i = 0; i < (1 << by); ++i) {
-    const int r = bitrev(i, by);
-    if (r >= tiles_y) continue;
-    for (int j = 0; j < (1 << bx); ++j) {
-      const int q = bitrev(j, bx);
-      if (q >= nb) continue;
-      for (int x = 8 * q; x < std::min(tiles_x, 8 * q + 8); ++x) h[static_cast<size_t>(k++)] = r * tiles_x + x;
-    }
-  }
+  const int ntiles = tiles_x * tiles_y, nb = (tiles_x + 7) / 8;
+  // (built on the device, stream-ordered ahead of the frame: no host copy, nothing waits)
   rt_context::FirstOrder t{tiles_x, tiles_y, nullptr};
-  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.order), h.size() * sizeof(int)));
-  RT_HIP(ctx, hipMemcpy(t.order, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(ntiles) + tiles_y + nb)));
+  RT_HIP(ctx, rtk::launch_first_order(t.order, t.order + rtk::order_table_ints(ntiles), tiles_x, tiles_y, ctx->stream));
   if (ctx->first_orders.size() >= 16) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->first_orders.front().order);
@@ -618,7 +603,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.donate = ctx->handover == 2 ? ctx->donate_max : 64;
     }
     bool first_order = false;
-    if (ctx->first_order && nframes == 1 && p.order == nullptr && !p.px_hdr && (p.nshards == 1 || p.interleave) && p.tiles_y > 1) {
+    if (ctx->first_order && nframes == 1 && p.order == nullptr && !p.px_hdr && (p.nshards == 1 || p.interleave) && p.tiles_y > 1 &&
+        p.tiles_y <= 4096 && p.tiles_x <= 32768) {
       // a frame nothing is known about: not top to bottom (the kernel reads the table like a view's order, with no deep tiles)
       if (int rc = get_first_order(ctx, p.tiles_x, p.tiles_y, &p.order)) return rc;
       p.deep_class = 0;

@@ -1083,4 +1083,49 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------------
+// The visiting order of a frame nothing is known about (api.cpp: get_first_order): tile rows in bit-reversed order and, inside a
+// row, blocks of 8 tiles in bit-reversed order of the blocks.  Built on the device (a pageable hipMemcpy of the 60 KB table took
+// milliseconds of the view's first frame on this stack).  rank[0 .. tiles_y): a row's place among the rows; rank[tiles_y ..): a
+// block's first column in the new order -- brute force, a thread per row / block (api.cpp caps the sizes).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int fo_bitrev(int i, int bits) {
+  int r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+__global__ void first_order_rank_kernel(int tiles_x, int tiles_y, int *rank) {
+  const int nb = (tiles_x + 7) / 8;
+  int by = 0, bx = 0;
+  while ((1 << by) < tiles_y) ++by;
+  while ((1 << bx) < nb) ++bx;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < tiles_y) {
+    const int mine = fo_bitrev(t, by);
+    int n = 0;
+    for (int r = 0; r < tiles_y; ++r) n += fo_bitrev(r, by) < mine ? 1 : 0;
+    rank[t] = n;
+  } else if (t < tiles_y + nb) {
+    const int q = t - tiles_y, mine = fo_bitrev(q, bx);
+    int off = 0;
+    for (int o = 0; o < nb; ++o)
+      if (fo_bitrev(o, bx) < mine) off += min(8, tiles_x - 8 * o);
+    rank[tiles_y + q] = off;
+  }
+}
+__global__ void first_order_fill_kernel(int tiles_x, int tiles_y, const int *rank, int *order) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tiles_x * tiles_y) return;
+  const int r = t / tiles_x, x = t - r * tiles_x;
+  order[rank[r] * tiles_x + rank[tiles_y + (x >> 3)] + (x & 7)] = t;
+}
+// `order`: order_table_ints(tiles) ints (the permutation, then zeroed class tables); `rank`: tiles_y + ceil(tiles_x / 8) ints of scratch
+hipError_t launch_first_order(int *order, int *rank, int tiles_x, int tiles_y, hipStream_t stream) {
+  const int ntiles = tiles_x * tiles_y, nb = (tiles_x + 7) / 8;
+  if (hipError_t e = hipMemsetAsync(order + ntiles, 0, sizeof(int) * (size_t)(order_table_ints(ntiles) - ntiles), stream); e != hipSuccess) return e;
+  hipLaunchKernelGGL(first_order_rank_kernel, dim3((tiles_y + nb + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank);
+  hipLaunchKernelGGL(first_order_fill_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank, order);
+  return hipGetLastError();
+}
+
 }  // namespace rtk

@@ -164,6 +164,11 @@ struct rt_prepared {
 };
 
 
+namespace rtk {
+// bvh_build.hip: the bit-reversed visiting order of a view's first frame, built on the device (api.cpp: get_first_order)
+hipError_t launch_first_order(int *order, int *rank, int tiles_x, int tiles_y, hipStream_t stream);
+}
+
 namespace rti {
 int fail(rt_context *ctx, const std::string &msg);
 int hip_fail(rt_context *ctx, hipError_t e, const char *what);
