@@ -14,11 +14,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "raytracers_amd", "csrc", "render_kernels.hip")
-DEFAULT = ["pooled_kernelILi1024ELb1ELb0ELb0ELi0E", "pooled_kernelILi1024ELb0ELb0ELb0ELi0E"]
-NAMES = {"pooled_kernelILi1024ELb1ELb0ELb0ELi0E": "pooled_kernel<1024, ALL_LDS> (rgbbox: the whole scene in LDS)",
-         "pooled_kernelILi1024ELb0ELb0ELb0ELi0E": "pooled_kernel<1024> (irreg, 10^6 spheres: node prefix in LDS, the rest through buffer_load)",
-         "pooled_kernelILi1024ELb0ELb0ELb0ELi1E": "pooled_kernel<1024, COLD> (small ordered frames)",
-         "pooled_kernelILi1024ELb0ELb0ELb0ELi2E": "pooled_kernel<1024, DONATE> (unordered frames)"}
+DEFAULT = ["pooled_kernelILi1024ELb1ELb0ELb0ELi0ELb0E", "pooled_kernelILi1024ELb0ELb0ELb0ELi0ELb0E", "pooled_kernelILi1024ELb1ELb0ELb1ELi0ELb1E",
+           "pooled_kernelILi1024ELb0ELb0ELb1ELi0ELb1E"]
+NAMES = {"pooled_kernelILi1024ELb1ELb0ELb0ELi0ELb0E": "pooled_kernel<1024, ALL_LDS> (rgbbox: the whole scene in LDS; batches, frames beyond the pixel list's gate)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi0ELb0E": "pooled_kernel<1024> (irreg, 10^6 spheres: node prefix in LDS, the rest through buffer_load)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi1ELb0E": "pooled_kernel<1024, COLD> (small ordered frames, pixel_order = 0)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi2ELb0E": "pooled_kernel<1024, DONATE> (unordered frames)",
+         "pooled_kernelILi1024ELb1ELb0ELb1ELi0ELb1E": "pooled_kernel<1024, ALL_LDS, SOLO, ORD> (rgbbox: ordered single frames through the pixel list)",
+         "pooled_kernelILi1024ELb0ELb0ELb1ELi0ELb1E": "pooled_kernel<1024, SOLO, ORD> (irreg: ordered single frames through the pixel list)",
+         "pooled_kernelILi1024ELb0ELb0ELb0ELi0ELb1E": "pooled_kernel<1024, ORD> (lists without a one-pixel class)"}
 
 FP32 = re.compile(r"^v_(add|sub|subrev|mul|fma|mac|fmac|mad)_(f32|legacy_f32)|^v_pk_(add|mul|fma)_f32")
 SEL = re.compile(r"^v_(cndmask|min|max|min3|max3|med3|cmp|cmpx)")
