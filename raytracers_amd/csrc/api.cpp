@@ -521,7 +521,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
           // the model's bounce cadences (0.1 us; measured, profiles/r05/README.md): a scene that lives in LDS, one that is read from L2
           const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-          static const int g_lds[5] = {25, 45, 65, 100, 240}, g_l2[5] = {45, 120, 170, 230, 330};
+          static const int g_lds[5] = {25, 45, 65, 100, 180}, g_l2[5] = {45, 120, 170, 230, 330};   // (LDS: 64 rays 24 us sorted straight through, 18 with the bulk zipped: e14)
           for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
           pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
           pol.nwaves = pl.grid_full * pl.waves;
