@@ -69,7 +69,41 @@ build/treelet_probe: tools/treelet_probe.cpp $(CSRC)/lane_core.h $(CSRC)/treelet
 	@mkdir -p build
 	$(CXX) $(HOSTFLAGS) -I$(CSRC) -o $@ tools/treelet_probe.cpp $(OBJ)/host_build.o
 
-tools: build/rtbench build/issue_peak build/queue_check build/donate_check build/treelet_probe build/hip_touch
+# the inequalities behind the CULL instantiations (lane_core.h: cull_limit) hammered with the product's binary32 code against __float128; in the CPU test suite
+build/cull_bound_check: tools/cull_bound_check.cpp $(CSRC)/lane_core.h $(CSRC)/rt_host.hpp $(OBJ)/host_build.o
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -fopenmp -I$(CSRC) -o $@ tools/cull_bound_check.cpp $(OBJ)/host_build.o -lquadmath
+
+# the pooled kernel's loop on emulated lanes with the culling rule: tests saved, pixels kept; in the CPU test suite
+build/cull_pooled: tools/cull_pooled.cpp $(CSRC)/lane_core.h $(CSRC)/rt_host.hpp $(OBJ)/host_build.o
+	@mkdir -p build
+	$(CXX) $(HOSTFLAGS) -I$(CSRC) -o $@ tools/cull_pooled.cpp $(OBJ)/host_build.o
+
+# host threads sharing one context and one prepared scene (the context lock): the plain build is in the GPU test suite ...
+build/ctx_threads: tools/ctx_threads.cpp include/ray.h include/rt_mi355x.h $(LIB)
+	@mkdir -p build
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -pthread -o $@ tools/ctx_threads.cpp -Lraytracers_amd -lray_mi355x -Wl,-rpath,'$$ORIGIN/../raytracers_amd'
+
+# ... and the same program over the library's HOST code built with -fsanitize=thread (device code and the HIP runtime are not
+# instrumented): build/tsan/libray_mi355x.so + build/tsan/ctx_threads, run on a GPU box by tools/gpu.sh tsan
+TSAN := -fsanitize=thread -g
+build/tsan/ctx_threads: tools/ctx_threads.cpp $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/host_build.cpp $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o
+	@mkdir -p build/tsan
+	$(HIPCC) $(HIPFLAGS) $(TSAN) -c $(CSRC)/api.cpp -o build/tsan/api.o
+	$(HIPCC) $(HIPFLAGS) $(TSAN) -c $(CSRC)/multi_gpu.cpp -o build/tsan/multi_gpu.o
+	/opt/rocm/lib/llvm/bin/clang++ $(HOSTFLAGS) $(TSAN) -c $(CSRC)/host_build.cpp -o build/tsan/host_build.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(TSAN) -o build/tsan/libray_mi355x.so $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o build/tsan/api.o build/tsan/multi_gpu.o build/tsan/host_build.o -ldl
+	/opt/rocm/lib/llvm/bin/clang++ -O1 -std=c++17 $(TSAN) -Iinclude -pthread -o $@ tools/ctx_threads.cpp -Lbuild/tsan -lray_mi355x -Wl,-rpath,'$$ORIGIN'
+
+# ... and once more with the locks compiled out (-DRT_NO_CONTEXT_LOCK): what the sanitizer says about the library WITHOUT them (the control run)
+build/tsan_nolock/ctx_threads: tools/ctx_threads.cpp $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/host_build.cpp $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o
+	@mkdir -p build/tsan_nolock
+	$(HIPCC) $(HIPFLAGS) $(TSAN) -DRT_NO_CONTEXT_LOCK -c $(CSRC)/api.cpp -o build/tsan_nolock/api.o
+	$(HIPCC) $(HIPFLAGS) $(TSAN) -DRT_NO_CONTEXT_LOCK -c $(CSRC)/multi_gpu.cpp -o build/tsan_nolock/multi_gpu.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(TSAN) -o build/tsan_nolock/libray_mi355x.so $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o build/tsan_nolock/api.o build/tsan_nolock/multi_gpu.o build/tsan/host_build.o -ldl
+	/opt/rocm/lib/llvm/bin/clang++ -O1 -std=c++17 $(TSAN) -Iinclude -pthread -o $@ tools/ctx_threads.cpp -Lbuild/tsan_nolock -lray_mi355x -Wl,-rpath,'$$ORIGIN'
+
+tools: build/ctx_threads build/rtbench build/issue_peak build/queue_check build/donate_check build/treelet_probe build/hip_touch build/cull_bound_check build/cull_pooled
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -68,11 +68,20 @@ int rt_context_rccl_ranks(rt_context *ctx);                 /* ranks of the RCCL
 void rt_context_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);       /* "" when no error; owned by ctx */
 /* What the last render entry of this context enqueued, for benches and profiles that want to assert which kernel ran (pixels never
- * depend on it): "family=pooled tickets=pixel-list|tiles-ordered|tiles-raster instantiation=ORD|ORD+SOLO|SOLO|COLD|DONATE|plain frames=..
- * tiles=.. grid=.. waves=.. counters=.. deep_class=.. deep_split=.. recording=0|1|2".  Owned by ctx; "" before the first render.
- * (A multi-device context: the first device's part.) */
+ * depend on it).  Owned by ctx; "" before the first render.  (A multi-device context: the first device's part.)  Values:
+ *   "family=none (memset)"        max_depth == 0: every pixel is the initial colour, no kernel
+ *   "family=none (no rows)"       the part owns no row of the image
+ *   "family=pixel" | "family=pixel (instrumented)" | "family=persistent"
+ *   "family=pooled tickets=T instantiation=I[+CULL] frames=.. tiles=.. grid=.. waves=.. counters=..[(turns)] deep_class=.. deep_split=.. recording=0|1|2"
+ *     T = pixel-list | tiles-ordered | tiles-bit-reversed (a view's first frame, first_order = 1) | tiles-raster
+ *     I = plain | SOLO | COLD | COLD+SOLO | DONATE | DONATE+SOLO | ORD | ORD+SOLO;  +CULL: boxes tested against the best hit so far
+ *     recording: 0 nothing, 1 the tiles' longest chains, 2 also every pixel's chain length */
 const char *rt_context_last_launch(const rt_context *ctx);
 int rt_context_sync(rt_context *ctx);
+/* Threads: every entry that takes a context holds that context's lock for the duration of the call (as a Futhark context does:
+ * SURVEY.md 8b) -- host threads may share a context, a prepared scene and a scene; their calls are serialised and their frames
+ * run on the context's one stream in the order the calls were admitted.  rt_last_error / rt_context_last_launch return
+ * pointers into the context: read them before another thread's call replaces the string (or use a context per thread). */
 int rt_context_set_variant(rt_context *ctx, int variant);
 /* Tuning knobs by name (see DESIGN.md "knobs"); unknown name -> error. */
 int rt_context_set_option(rt_context *ctx, const char *name, int64_t value);

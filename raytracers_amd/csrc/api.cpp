@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -281,7 +282,7 @@ int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves
   if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1) return 0;
   if (!to->have_classes) {
     if (to->classes_pending && ps->classes_pinned && to->classes_slot >= 0) {
-      hipError_t q = may_wait ? hipEventSynchronize(to->classes_event) : hipEventQuery(to->classes_event);
+      hipError_t q = (may_wait || ctx->sync_policy) ? hipEventSynchronize(to->classes_event) : hipEventQuery(to->classes_event);
       if (q == hipSuccess) {
         std::memcpy(to->classes, ps->classes_pinned + kClassSlotInts * to->classes_slot, sizeof to->classes);
         to->have_classes = true;
@@ -329,12 +330,27 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
   return 0;
 }
 
+// May this launch cull (lane_core.h: cull_limit)?  The scene's guards (rt_prepared::cull), the launch shape the CULL instantiations
+// exist for, and every camera origin of the launch inside the scene guard -- a batch's cameras are read from the context's pinned
+// copy of them (stage_cams); cameras that live only on the device switch culling off.
+bool cull_allowed(const rt_context *ctx, const rt_prepared *ps, const Plan &pl, const rtk::KParams &p, const float *cams_dev, int nframes) {
+  if (ctx->cull == 0 || !ps->cull.ok || pl.variant != RT_VARIANT_POOLED || pl.waves != 16) return false;
+  if (ctx->cull < 0 && pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph) return false;
+  if (cams_dev == nullptr) return rt::cull_origin_ok(ps->cull, &p.cam.ox);
+  if (cams_dev != ctx->cams_dev || ctx->cams_host == nullptr) return false;
+  for (int f = 0; f < nframes; ++f)
+    if (!rt::cull_origin_ok(ps->cull, ctx->cams_host + 12 * f)) return false;
+  return true;
+}
+
 }  // namespace
 
 int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                         int32_t part, int32_t nparts, int32_t *out_dev, bool stats, const float *cam12, int32_t nframes,
                         int64_t frame_stride, const float *cams_dev, bool inplace) {
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
+  RT_LOCK(ctx);                                                  // (multi_gpu.cpp calls this on the children of a parent it holds)
+  RT_LOCK_PS(ps);                                                // the view's record / order / pixel list are updated below
   if (!out_dev) return fail(ctx, "null output pointer");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30))
     return fail(ctx, "image size out of range");
@@ -359,7 +375,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.out = out_dev;
   p.stats = ctx->stats_dev;
   p.nframes = 1;
-  if (p.rows_local == 0) return 0;
+  if (p.rows_local == 0) {
+    ctx->last_launch = "family=none (no rows)";
+    return 0;
+  }
   const int64_t frame_elems = inplace ? h * w : static_cast<int64_t>(p.rows_local) * p.w;
   if (nframes < 1 || (nframes > 1 && (frame_stride < frame_elems || frame_stride * nframes >= (int64_t(1) << 31))))
     return fail(ctx, "bad batch: nframes >= 1, frame_stride >= rows * w (in place: h * w), nframes * frame_stride < 2^31");
@@ -383,6 +402,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
                                    sizeof(int32_t) * static_cast<size_t>(rows * w), ctx->stream));
       }
     }
+    ctx->last_launch = "family=none (memset)";
     return 0;
   }
   Plan pl{};
@@ -610,6 +630,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.deep_class = 0;
       first_order = true;
     }
+    // Culling by the best hit so far (the CULL instantiations; lane_core.h: cull_limit): where the scene's and the
+    // camera's guards pass.  Auto leaves wholly LDS-resident scenes alone: their walks are short and LDS-fast, and the limit's three
+    // instructions per item cost more than the tests it saves (rgbbox 1000 x 1000: -3 % box tests; tools/cull_pooled.cpp).
+    if (cull_allowed(ctx, ps, pl, p, cams_dev, nframes)) {
+      p.cull = 1;
+      p.cull_c2 = ps->cull.c2;
+      p.cull_kappa = ps->cull.kappa;
+    }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     {
       // (which instantiation launch_pooled picks, in its own order of precedence)
@@ -617,8 +645,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       const char *inst = p.px_hdr ? (p.solo ? "ORD+SOLO" : "ORD") : (p.cold && pl.waves == 16) ? (single_px ? "COLD+SOLO" : "COLD")
                          : (p.donate && pl.waves == 16) ? (single_px ? "DONATE+SOLO" : "DONATE") : (single_px ? "SOLO" : "plain");
       char buf[256];
-      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s instantiation=%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
-                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), inst, p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
+      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s instantiation=%s%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
+                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), inst, p.cull ? "+CULL" : "", p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
                     p.interleave ? "(turns)" : "", p.px_hdr ? 0 : p.deep_class, p.px_hdr ? 0 : p.deep_split, p.cost ? (p.cost_px ? 2 : 1) : 0);
       ctx->last_launch = buf;
     }
@@ -734,6 +762,7 @@ extern "C" const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->
 extern "C" const char *rt_context_last_launch(const rt_context *ctx) { return ctx ? ctx->last_launch.c_str() : ""; }
 
 extern "C" int rt_context_sync(rt_context *ctx) {
+  RT_LOCK(ctx);
   if (!ctx) return 1;
   if (ctx->group) return rti::group_sync(ctx);   // every frame ends on the parent's stream, synchronised last
   // Frames take well under a millisecond: poll briefly (a frame's worth) before falling back to the
@@ -758,6 +787,7 @@ extern "C" int rt_context_sync(rt_context *ctx) {
 }
 
 extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
+  RT_LOCK(ctx);
   if (!ctx) return 1;
   if (variant < RT_VARIANT_AUTO || variant > RT_VARIANT_POOLED) return fail(ctx, "unknown variant");
   ctx->variant = variant;
@@ -766,6 +796,7 @@ extern "C" int rt_context_set_variant(rt_context *ctx, int variant) {
 }
 
 extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t value) {
+  RT_LOCK(ctx);
   if (!ctx || !name) return 1;
   if (ctx->group) {
     const int grc = rti::group_set_option(ctx, name, value);
@@ -852,6 +883,10 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_hold = v & 0x1f;
   } else if (k == "px_solo_div") {
     ctx->px_solo_div = std::max(1, std::min(4096, v));
+  } else if (k == "cull") {
+    ctx->cull = std::max(-1, std::min(1, v));
+  } else if (k == "sync_policy") {
+    ctx->sync_policy = v != 0;
   } else {
     return fail(ctx, "unknown option: " + k);
   }
@@ -860,6 +895,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
 
 extern "C" int rt_context_device_info(const rt_context *ctx, int *device, int *num_cu, int *lds_bytes, char *name,
                                       int name_len) {
+  RT_LOCK(const_cast<rt_context *>(ctx));
   if (!ctx) return 1;
   if (device) *device = ctx->device;
   if (num_cu) *num_cu = ctx->num_cu;
@@ -873,6 +909,7 @@ extern "C" int rt_context_device_info(const rt_context *ctx, int *device, int *n
 
 // ------------------------------------------------------------------------------------ scenes
 static int new_scene(rt_context *ctx, rt_scene **out, rt::SceneDesc &&d) {
+  RT_LOCK(ctx);
   if (!ctx || !out) return fail(ctx, "null argument");
   auto *s = new rt_scene;
   s->desc = std::move(d);
@@ -882,11 +919,13 @@ static int new_scene(rt_context *ctx, rt_scene **out, rt::SceneDesc &&d) {
 extern "C" int rt_scene_rgbbox(rt_context *ctx, rt_scene **out) { return new_scene(ctx, out, rt::make_rgbbox()); }
 extern "C" int rt_scene_irreg(rt_context *ctx, rt_scene **out) { return new_scene(ctx, out, rt::make_floor(100, 600.0f)); }
 extern "C" int rt_scene_floor(rt_context *ctx, rt_scene **out, int n, float k) {
+  RT_LOCK(ctx);
   if (n < 2 || n > 4096) return fail(ctx, "floor scene: n out of range (2..4096)");
   return new_scene(ctx, out, rt::make_floor(n, k));
 }
 extern "C" int rt_scene_from_spheres(rt_context *ctx, rt_scene **out, const float *spheres7, int64_t n,
                                      const float look_from[3], const float look_at[3], float fov) {
+  RT_LOCK(ctx);
   if (!spheres7 || !look_from || !look_at) return fail(ctx, "null argument");
   if (n < 2 || n > (int64_t(1) << rtk::kMaxSpheresLog2)) return fail(ctx, "scene needs 2 .. 2^26 spheres");   // (treelet.h: the builders' index fields)
   rt::SceneDesc d;
@@ -901,6 +940,7 @@ extern "C" int64_t rt_scene_num_spheres(const rt_scene *scene) {
   return scene ? static_cast<int64_t>(scene->desc.spheres.size()) : 0;
 }
 extern "C" int rt_scene_free(rt_context *ctx, rt_scene *scene) {
+  RT_LOCK(ctx);
   if (scene)
     for (auto &c : scene->copies) {
       (void)hipSetDevice(c.device);
@@ -913,6 +953,7 @@ extern "C" int rt_scene_free(rt_context *ctx, rt_scene *scene) {
 
 // ------------------------------------------------------------------------------------ prepare_scene
 extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, int64_t w, const rt_scene *scene) {
+  RT_LOCK(ctx);
   if (!ctx || !out || !scene) return fail(ctx, "null argument");
   if (h <= 0 || w <= 0) return fail(ctx, "image size must be positive");
   if (scene->desc.spheres.size() < 2) return fail(ctx, "scene needs at least 2 spheres");
@@ -1016,6 +1057,16 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     // the host staging vectors die at scope exit: drain the copies first
     e = hipStreamSynchronize(ctx->stream);
   }
+  if (!rc && e == hipSuccess) {
+    // culling by the best hit (lane_core.h: cull_limit): the scene's guards and constants; the spheres' side once per scene
+    std::lock_guard<std::mutex> lock(scene->mu);
+    if (!scene->cull_done) {
+      scene->cull = rt::cull_scene_constants(scene->desc.spheres, 0);
+      scene->cull_done = true;
+    }
+    ps->cull = scene->cull;
+    ps->cull.ok = ps->cull.ok && ps->height <= static_cast<int>(log2f(static_cast<float>(n))) + 2;   // every box contains its subtree (bvh.fut:47)
+  }
   const int grc = ctx->group ? rti::group_prepare_end(ctx, ps.get()) : 0;   // (joins the replica builds whatever happened here)
   if (rc || e != hipSuccess) {
     rt_prepared_free(ctx, ps.release());
@@ -1030,6 +1081,7 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
 }
 
 extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
+  RT_LOCK(ctx);
   if (!ps) return 0;
   if (!ps->replicas.empty()) rti::group_prepared_free(ctx, ps);
   if (ctx) {
@@ -1054,6 +1106,7 @@ extern "C" int32_t rt_prepared_height(const rt_prepared *ps) { return ps ? ps->h
 
 extern "C" int rt_prepared_get_bvh(rt_context *ctx, const rt_prepared *ps, float *L7, float *bmin, float *bmax,
                                    int32_t *left, int32_t *right, int32_t *parent) {
+  RT_LOCK(ctx);
   if (!ctx || !ps) return fail(ctx, "null argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1068,6 +1121,7 @@ extern "C" int rt_prepared_get_bvh(rt_context *ctx, const rt_prepared *ps, float
 }
 
 extern "C" int rt_prepared_get_camera(rt_context *ctx, const rt_prepared *ps, float cam12[12]) {
+  RT_LOCK(ctx);
   if (!ctx || !ps || !cam12) return fail(ctx, "null argument");
   std::memcpy(cam12, &ps->cam, sizeof(rt::Camera));
   return 0;
@@ -1078,6 +1132,7 @@ extern "C" int rt_prepared_get_camera(rt_context *ctx, const rt_prepared *ps, fl
 // devices (multi_gpu.cpp); it does not nest a caller's partition inside its own.
 static int render_entry(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                         int32_t part, int32_t nparts, int32_t *out_dev, const float *cam12) {
+  RT_LOCK(ctx);
   if (ctx && ctx->group) {
     if (!ps) return fail(ctx, "null prepared scene");
     if (part != 0 || nparts != 1) return fail(ctx, "a multi-device context renders whole frames: it partitions them itself");
@@ -1107,6 +1162,7 @@ extern "C" int rt_render_image(rt_context *ctx, const rt_prepared *objs, int64_t
 // the asynchronous upload then never reads memory the caller may already have changed or freed (pinned caller memory
 // would otherwise be read when the copy EXECUTES).
 int rti::stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const float **cams_dev) {
+  RT_LOCK(ctx);
   *cams_dev = nullptr;
   if (!cams12) return 0;
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1139,6 +1195,7 @@ int rti::stage_cams(rt_context *ctx, const float *cams12, int32_t nframes, const
 extern "C" int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                                int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
                                int32_t *out_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
   if (nframes < 1 || nframes > 4096) return fail(ctx, "rt_render_batch: 1 .. 4096 frames");
   if (ctx->group) {   // every device renders its rows of ALL the frames in one launch; one gather, one assembly launch
@@ -1157,6 +1214,7 @@ extern "C" int rt_render_batch(rt_context *ctx, const rt_prepared *ps, int64_t h
 extern "C" int rt_render_part_inplace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth, int32_t rows_per_tile,
                                       int32_t part, int32_t nparts, int32_t nframes, const float *cams12, int64_t frame_stride,
                                       int32_t *image_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !ps) return fail(ctx, "null context or prepared scene");
   if (ctx->group) return fail(ctx, "a multi-device context renders whole frames: it partitions them itself (option gather=3 stores in place)");
   if (nframes < 1 || nframes > 4096) return fail(ctx, "rt_render_part_inplace: 1 .. 4096 frames");
@@ -1171,6 +1229,7 @@ extern "C" int rt_render_part_inplace(rt_context *ctx, const rt_prepared *ps, in
 // (rt_device_alloc's pointer, i.e. the base of a hipMalloc block) as 64 opaque bytes, the other ranks import them and get a
 // device pointer they can hand to rt_render_part_inplace.
 extern "C" int rt_ipc_export(rt_context *ctx, void *dev, unsigned char handle64[64]) {
+  RT_LOCK(ctx);
   if (!ctx || !dev || !handle64) return fail(ctx, "null argument");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI passes an IPC handle as 64 bytes");
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1180,6 +1239,7 @@ extern "C" int rt_ipc_export(rt_context *ctx, void *dev, unsigned char handle64[
   return 0;
 }
 extern "C" int rt_ipc_import(rt_context *ctx, const unsigned char handle64[64], void **out_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !handle64 || !out_dev) return fail(ctx, "null argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   hipIpcMemHandle_t hnd;
@@ -1188,6 +1248,7 @@ extern "C" int rt_ipc_import(rt_context *ctx, const unsigned char handle64[64], 
   return 0;
 }
 extern "C" int rt_ipc_close(rt_context *ctx, void *imported_dev) {
+  RT_LOCK(ctx);
   if (!ctx) return 1;
   if (!imported_dev) return 0;
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1202,6 +1263,7 @@ extern "C" int64_t rt_part_rows(int64_t h, int32_t rows_per_tile, int32_t part, 
 
 extern "C" int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t part, int32_t nparts,
                              const int32_t *part_dev, int32_t *image_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !part_dev || !image_dev) return fail(ctx, "null argument");
   if (rows_per_tile <= 0 || nparts <= 0 || part < 0 || part >= nparts) return fail(ctx, "bad row-tile partition");
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1213,6 +1275,7 @@ extern "C" int rt_place_part(rt_context *ctx, int64_t h, int64_t w, int32_t rows
 
 extern "C" int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts,
                                       int64_t part_stride, const int32_t *stacked_dev, int32_t *image_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !stacked_dev || !image_dev) return fail(ctx, "null argument");
   if (rows_per_tile <= 0 || nparts <= 0 || h <= 0 || w <= 0) return fail(ctx, "bad row-tile partition");
   int64_t need = 0;
@@ -1227,6 +1290,7 @@ extern "C" int rt_place_parts_strided(rt_context *ctx, int64_t h, int64_t w, int
 extern "C" int rt_place_parts_batch(rt_context *ctx, int64_t h, int64_t w, int32_t rows_per_tile, int32_t nparts, int64_t part_stride,
                                     int32_t nframes, int64_t frame_stride_in, int64_t frame_stride_out, const int32_t *stacked_dev,
                                     int32_t *images_dev) {
+  RT_LOCK(ctx);
   if (!ctx || !stacked_dev || !images_dev) return fail(ctx, "null argument");
   if (rows_per_tile <= 0 || nparts <= 0 || h <= 0 || w <= 0 || nframes < 1) return fail(ctx, "bad row-tile partition");
   int64_t need = 0;
@@ -1248,6 +1312,7 @@ extern "C" int rt_place_parts(rt_context *ctx, int64_t h, int64_t w, int32_t row
 
 extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                                uint64_t stats3[3]) {
+  RT_LOCK(ctx);
   if (!ctx || !ps || !stats3) return fail(ctx, "null argument");
   if (h <= 0 || w <= 0 || h > (1 << 20) || w > (1 << 20) || h * w > (int64_t(1) << 30)) return fail(ctx, "image size out of range");
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1273,7 +1338,9 @@ extern "C" int rt_render_stats(rt_context *ctx, const rt_prepared *ps, int64_t h
 // view's longest chains by the difference between the two (~7 against ~4.5 us per bounce).
 extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                                uint64_t *records, int32_t max_waves, int32_t *num_waves) {
+  RT_LOCK(ctx);
   if (!ctx || !ps || !records || !num_waves) return fail(ctx, "null argument");
+  RT_LOCK_PS(ps);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   Plan pl{};
   const int saved = ctx->variant;
@@ -1365,6 +1432,11 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
         }
       }
     nw = pl.grid * pl.waves;
+    if (cull_allowed(ctx, ps, pl, p, nullptr, 1)) {   // as enqueue_render launches this view
+      p.cull = 1;
+      p.cull_c2 = ps->cull.c2;
+      p.cull_kappa = ps->cull.kappa;
+    }
     e = rtk::launch_pooled(p, true, pl.grid, pl.waves, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(records, trace, sizeof(unsigned long long) * rtk::kTraceWords * static_cast<size_t>(nw), hipMemcpyDeviceToHost);
@@ -1380,6 +1452,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
 extern "C" int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h, int64_t w, int32_t max_depth,
                                int32_t rows_per_tile, int32_t part, int32_t nparts, int32_t *out_dev, int32_t warmup,
                                int32_t iters, float *ms_out) {
+  RT_LOCK(ctx);
   if (!ctx || !ms_out || iters <= 0 || warmup < 0) return fail(ctx, "bad argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < warmup; ++i)
@@ -1403,12 +1476,14 @@ extern "C" int rt_render_timed(rt_context *ctx, const rt_prepared *ps, int64_t h
 
 // ------------------------------------------------------------------------------------ buffers
 extern "C" int rt_device_alloc(rt_context *ctx, void **out_dev, int64_t bytes) {
+  RT_LOCK(ctx);
   if (!ctx || !out_dev || bytes < 0) return fail(ctx, "bad argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipMalloc(out_dev, std::max<int64_t>(bytes, 16)));
   return 0;
 }
 extern "C" int rt_device_free(rt_context *ctx, void *dev) {
+  RT_LOCK(ctx);
   if (!ctx) return 1;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1416,6 +1491,7 @@ extern "C" int rt_device_free(rt_context *ctx, void *dev) {
   return 0;
 }
 extern "C" int rt_copy_to_host(rt_context *ctx, void *dst_host, const void *src_dev, int64_t bytes) {
+  RT_LOCK(ctx);
   if (!ctx || !dst_host || !src_dev || bytes < 0) return fail(ctx, "bad argument");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
@@ -1432,6 +1508,7 @@ struct futhark_context_config {
   int debugging = 0, logging = 0, profiling = 0;
 };
 struct futhark_context {
+  std::recursive_mutex mu;   // Futhark's context lock: every futhark_* entry holds it (the image pool, the pending error, the counters)
   rt_context *rt = nullptr;
   // freed images are kept for reuse: main.c frees and re-renders every run, and a
   // hipFree/hipMalloc pair per frame costs more than the frame itself
@@ -1450,6 +1527,12 @@ struct futhark_i32_2d {
   int32_t *dev = nullptr;
   int64_t shape[2] = {0, 0};
 };
+
+#ifndef RT_NO_CONTEXT_LOCK
+#define FUT_LOCK(ctx) std::unique_lock<std::recursive_mutex> fut_lock_ = (ctx) ? std::unique_lock<std::recursive_mutex>((ctx)->mu) : std::unique_lock<std::recursive_mutex>()
+#else
+#define FUT_LOCK(ctx) (void)(ctx)
+#endif
 
 namespace {
 int fut_fail(futhark_context *ctx, int rc) {
@@ -1515,6 +1598,7 @@ extern "C" void futhark_context_free(struct futhark_context *ctx) {
   delete ctx;
 }
 extern "C" char *futhark_context_get_error(struct futhark_context *ctx) {
+  FUT_LOCK(ctx);
   if (!ctx || ctx->pending.empty()) return nullptr;
   char *s = static_cast<char *>(std::malloc(ctx->pending.size() + 1));
   if (s) std::memcpy(s, ctx->pending.c_str(), ctx->pending.size() + 1);
@@ -1522,10 +1606,12 @@ extern "C" char *futhark_context_get_error(struct futhark_context *ctx) {
   return s;
 }
 extern "C" int futhark_context_sync(struct futhark_context *ctx) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt) return 1;
   return fut_fail(ctx, rt_context_sync(ctx->rt));
 }
 extern "C" char *futhark_context_report(struct futhark_context *ctx) {
+  FUT_LOCK(ctx);
   char buf[512];
   int dev = -1, cus = 0, lds = 0;
   char name[64] = "";
@@ -1540,6 +1626,7 @@ extern "C" char *futhark_context_report(struct futhark_context *ctx) {
 }
 
 extern "C" int futhark_entry_rgbbox(struct futhark_context *ctx, struct futhark_opaque_scene **out0) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !out0) return 1;
   auto o = std::make_unique<futhark_opaque_scene>();
   if (int rc = rt_scene_rgbbox(ctx->rt, &o->s)) return fut_fail(ctx, rc);
@@ -1547,6 +1634,7 @@ extern "C" int futhark_entry_rgbbox(struct futhark_context *ctx, struct futhark_
   return 0;
 }
 extern "C" int futhark_entry_irreg(struct futhark_context *ctx, struct futhark_opaque_scene **out0) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !out0) return 1;
   auto o = std::make_unique<futhark_opaque_scene>();
   if (int rc = rt_scene_irreg(ctx->rt, &o->s)) return fut_fail(ctx, rc);
@@ -1555,6 +1643,7 @@ extern "C" int futhark_entry_irreg(struct futhark_context *ctx, struct futhark_o
 }
 extern "C" int futhark_entry_prepare_scene(struct futhark_context *ctx, struct futhark_opaque_prepared_scene **out0,
                                            const int64_t in0, const int64_t in1, const struct futhark_opaque_scene *in2) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !out0 || !in2) return 1;
   auto o = std::make_unique<futhark_opaque_prepared_scene>();
   if (int rc = rt_prepare_scene(ctx->rt, &o->p, in0, in1, in2->s)) return fut_fail(ctx, rc);
@@ -1564,6 +1653,7 @@ extern "C" int futhark_entry_prepare_scene(struct futhark_context *ctx, struct f
 }
 extern "C" int futhark_entry_render(struct futhark_context *ctx, struct futhark_i32_2d **out0, const int64_t in0,
                                     const int64_t in1, const struct futhark_opaque_prepared_scene *in2) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !out0 || !in2) return 1;
   auto img = std::make_unique<futhark_i32_2d>();
   void *dev = nullptr;
@@ -1587,10 +1677,12 @@ extern "C" int futhark_entry_render(struct futhark_context *ctx, struct futhark_
   return 0;
 }
 extern "C" int futhark_values_i32_2d(struct futhark_context *ctx, struct futhark_i32_2d *arr, int32_t *data) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !arr || !data) return 1;
   return fut_fail(ctx, rt_copy_to_host(ctx->rt, data, arr->dev, static_cast<int64_t>(sizeof(int32_t)) * arr->shape[0] * arr->shape[1]));
 }
 extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i32_2d *arr) {
+  FUT_LOCK(ctx);
   if (!arr) return 0;
   int rc = 0;
   if (ctx && ctx->rt && arr->dev) {
@@ -1601,6 +1693,7 @@ extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i
   return fut_fail(ctx, rc);
 }
 extern "C" struct futhark_i32_2d *futhark_new_i32_2d(struct futhark_context *ctx, const int32_t *data, int64_t dim0, int64_t dim1) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt || !data || dim0 < 0 || dim1 < 0) return nullptr;
   auto arr = std::make_unique<futhark_i32_2d>();
   arr->shape[0] = dim0; arr->shape[1] = dim1;
@@ -1615,6 +1708,7 @@ extern "C" struct futhark_i32_2d *futhark_new_i32_2d(struct futhark_context *ctx
 }
 extern "C" int32_t *futhark_values_raw_i32_2d(struct futhark_context *, struct futhark_i32_2d *arr) { return arr ? arr->dev : nullptr; }
 extern "C" int futhark_context_clear_caches(struct futhark_context *ctx) {
+  FUT_LOCK(ctx);
   if (!ctx || !ctx->rt) return 1;
   if (rt_context_sync(ctx->rt)) return fut_fail(ctx, 1);
   for (auto &im : ctx->image_pool) (void)rt_device_free(ctx->rt, im.second);
@@ -1630,12 +1724,14 @@ extern "C" const int64_t *futhark_shape_i32_2d(struct futhark_context *, struct 
   return arr ? arr->shape : nullptr;
 }
 extern "C" int futhark_free_opaque_prepared_scene(struct futhark_context *ctx, struct futhark_opaque_prepared_scene *obj) {
+  FUT_LOCK(ctx);
   if (!obj) return 0;
   if (ctx && ctx->rt) rt_prepared_free(ctx->rt, obj->p);
   delete obj;
   return 0;
 }
 extern "C" int futhark_free_opaque_scene(struct futhark_context *ctx, struct futhark_opaque_scene *obj) {
+  FUT_LOCK(ctx);
   if (!obj) return 0;
   rt_scene_free(ctx ? ctx->rt : nullptr, obj->s);
   delete obj;

@@ -370,4 +370,54 @@ int64_t part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts
   return rows;
 }
 
+// ---- culling constants (rt_host.hpp; the derivation is DESIGN.md 3.5) ----
+CullConst cull_scene_constants(const std::vector<Sphere> &ts, int height) {
+  CullConst c;
+  const size_t n = ts.size();
+  if (n < 2) return c;
+  const int sweeps = static_cast<int>(log2f(static_cast<float>(n))) + 2;   // bvh.fut:47
+  if (height > sweeps) return c;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double r_min = INFINITY, r_max = 0.0, c_max = 0.0;
+  for (const Sphere &s : ts) {
+    const double p[3] = {s.px, s.py, s.pz}, r = s.radius;
+    if (!(r >= 0x1p-20) || !std::isfinite(r)) return c;
+    r_min = std::min(r_min, r);
+    r_max = std::max(r_max, r);
+    for (int a = 0; a < 3; ++a) {
+      if (!std::isfinite(p[a])) return c;
+      lo[a] = std::min(lo[a], p[a]);
+      hi[a] = std::max(hi[a], p[a]);
+      c_max = std::max(c_max, std::fabs(p[a]) + r);
+    }
+  }
+  if (c_max > 0x1p40) return c;
+  double diag2 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    c.centre[a] = 0.5 * (lo[a] + hi[a]);
+    diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+  }
+  c.reach = 0.5 * std::sqrt(diag2) * (1.0 + 0x1p-20) + r_max;
+  c.r_min = r_min;
+  if (2.0 * c.reach > 0x1p15 * r_min) return c;
+  // rho' <= c2' a best^2 + c0' with c2' = 2^-16 / r_min, c0' = 2^-16 r_max^2 / r_min + 2^-18 r_max + 2^-24 C_max; both carry 2^-21 for the
+  // rounding of tmin and of the limit itself, and 1 % for the roundings of W2 and of the two fused multiply-adds
+  const double c2 = 1.01 * (0x1p-16 / r_min + 0x1p-21);
+  const double c0 = 1.01 * (0x1p-16 * r_max * r_max / r_min + 0x1p-18 * r_max + 0x1p-24 * c_max + 0x1p-21);
+  c.c2 = std::nextafter(static_cast<float>(c2), INFINITY);
+  c.kappa = std::nextafter(static_cast<float>(c0 / (c2 * 0.015625)), INFINITY);   // / kCullALo: W2 kappa >= max|1 / d_k| c0 for every a >= 2^-6
+  c.ok = std::isfinite(c.c2) && std::isfinite(c.kappa);
+  return c;
+}
+
+bool cull_origin_ok(const CullConst &c, const float origin[3]) {
+  if (!c.ok) return false;
+  double d2 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    if (!std::isfinite(origin[a])) return false;
+    d2 += (origin[a] - c.centre[a]) * (origin[a] - c.centre[a]);
+  }
+  return std::sqrt(d2) * (1.0 + 0x1p-20) + c.reach <= 0x1p15 * c.r_min;
+}
+
 }  // namespace rt

@@ -88,7 +88,9 @@ RT_HD Ray primary_ray(const Cam &c, int col, int row, int width, int height) {
 // (The per-axis swap on `invD < 0` must stay a select: with a zero direction component,
 // 0 * inf = NaN bounds arise that min/max-based swapping would treat differently.)
 typedef float rt_f2 __attribute__((vector_size(8)));
-RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+// `tclamp`: the interval's upper end.  kTMax gives aabb_hit itself (box_hit below); the CULL instantiations of the pooled kernel pass
+// min(kTMax, a proven lower bound on every sphere root the box's subtree could still contribute) -- see cull_limit.
+RT_HD bool box_hit_clamped(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tclamp) {
   // x and y as a pair: two packed subtracts + two packed multiplies (v_pk_add/mul_f32 round
   // each lane exactly like the scalar instructions)
   const rt_f2 o2 = {r.ox, r.oy}, i2 = {r.ix, r.iy};
@@ -97,12 +99,42 @@ RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, flo
   const float t0z = (loz - r.oz) * r.iz, t1z = (hiz - r.oz) * r.iz;
   const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
   float tmin = fmaxf(nx ? t1[0] : t0[0], 0.0f);
-  float tmax = fminf(nx ? t0[0] : t1[0], kTMax);
+  float tmax = fminf(nx ? t0[0] : t1[0], tclamp);
   tmin = fmaxf(ny ? t1[1] : t0[1], tmin);
   tmax = fminf(ny ? t0[1] : t1[1], tmax);
   tmin = fmaxf(nz ? t1z : t0z, tmin);
   tmax = fminf(nz ? t0z : t1z, tmax);
   return !(tmax <= tmin);
+}
+RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  return box_hit_clamped(r, lox, loy, loz, hix, hiy, hiz, kTMax);
+}
+
+// ---- culling by the best hit so far (the CULL instantiations of the pooled kernel) -------------------------
+// The reference's fold tests every leaf whose ancestors' boxes pass with the FIXED interval (0, 1e9) (ray.fut:77) -- it never
+// narrows the interval.  Only its RESULT is the contract: the smallest accepted root, ties to the lowest leaf.  A subtree may
+// therefore be skipped when every root any of its spheres could produce is proven LARGER than a root already found.
+//
+// The bound (proof and constants: DESIGN.md 3.5; tools/cull_bound_check.cpp hammers the two inequalities it rests on).  For a
+// ray (o, d) and a sphere (p, r) let g be ANY root sphere_root computes in binary32, P = o + g d the exact point at that
+// parameter, D = |o - p|, a = d.d.  Then
+//     | |P - p|^2 - r^2 |  <=  2^-18 (D^2 + r^2)                                                     (E1)
+// i.e. P lies within rho = 2^-18 (D^2 / r + r) of the sphere, hence inside any box that contains the sphere's binary32 box
+// (pos -+ r, rounded: off by at most 2^-24 max|coordinate|) widened by rho' = rho + 2^-24 C_max on every side, hence
+//     g  >=  tmin(box) (1 - 3.01 * 2^-24)  -  rho' max_k |1 / d_k|                                   (E2)
+// with tmin the entry parameter box_hit computes.  With g <= best (only such a root could matter), D <= 2 (a best^2 + r^2)^(1/2)
+// under the scene guard of cull_scene_constants, and the right-hand side exceeds `best` whenever
+//     tmin  >=  best + W2 (best^2 + kappa),    W2 = max_k |1 / d_k| * a * c2
+// c2 and kappa being per-scene constants.  A box is tested against min(kTMax, that limit) instead of kTMax: one instruction
+// stream, and a box that fails only against the limit is a subtree whose every root is > best -- it cannot win or tie.
+// Requires every box to contain the boxes of the spheres below it (tree height <= the reference's number of sweeps).
+constexpr float kCullALo = 1.0f / 64.0f, kCullAHi = 1048576.0f;   // a = d.d outside [2^-6, 2^20]: the ray is not culled
+RT_HD float cull_weight(const Ray &r, float c2) {                 // W2 of a ray (inf: never cull)
+  const float m = fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz));
+  return (r.a >= kCullALo && r.a <= kCullAHi) ? m * r.a * c2 : kNoHit;
+}
+RT_HD float cull_limit(float best, float w2, float kappa) {       // the interval's upper end for a slot whose best root is `best`
+  return fminf(__builtin_fmaf(w2, __builtin_fmaf(best, best, kappa), best), kTMax);
 }
 
 // The root closest_hit would accept for this sphere if its running t_max were large

@@ -170,6 +170,7 @@ extern "C" int rt_context_num_devices(const rt_context *ctx) {
 }
 
 extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
+  RT_LOCK(ctx);
   if (!ctx || !ctx->group || ctx->group->kids.size() < 2) return ctx && ctx->group && ctx->group->gather == 2 ? "rccl" : "none";
   rt_group *g = ctx->group;
   // (auto: what the last frame was carried by -- an image the other devices cannot be shown to reach goes through the gather)
@@ -181,6 +182,7 @@ extern "C" const char *rt_context_gather_mode(rt_context *ctx) {
 
 // ranks of the RCCL communicator that carries the gather (0: none -- one device, direct stores or peer copies, or RCCL not loaded yet)
 extern "C" int rt_context_rccl_ranks(rt_context *ctx) {
+  RT_LOCK(ctx);
   if (!ctx || !ctx->group || ctx->group->rccl_failed) return 0;
   return static_cast<int>(ctx->group->comms.size());
 }

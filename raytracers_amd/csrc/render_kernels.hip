@@ -397,6 +397,12 @@ __device__ __forceinline__ float4 lds_load16(unsigned a) {
 }
 __device__ __forceinline__ unsigned lds_load4(unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(a); }
 
+// (CULL exists here and is NOT used, kSoloCull: a lone ray's box items are all expanded before its first sphere test -- the leaves sit at
+// the bottom of the tree, and the leaf list of one ray never reaches a batch of 64 -- so its best root is still 1e9 while the boxes
+// are walked: the limit never bites and costs its instructions on the frame's critical path.  Measured with it on, round 6:
+// irreg 1000 x 1000 one frame at a time 0.249 -> 0.256 ms, 500 x 500 0.218 -> 0.226; profiles/r06/exp/e1_cull_ab.txt.)
+constexpr bool kSoloCull = false;
+template <bool CULL>
 __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned smem_lds, unsigned wbase_lds, float ox, float oy, float oz,
                                                      float dx, float dy, float dz, float lr, float lg, float lb, int pix, int depth,
                                                      int ptile) {
@@ -417,6 +423,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
   const __amdgpu_buffer_rsrc_t rs_sph = make_rsrc(pp->sph, (unsigned)pp->n_sph * 16u);
   const __amdgpu_buffer_rsrc_t rs_col = make_rsrc(pp->col, (unsigned)pp->n_sph * 16u);
   const int max_depth = pp->max_depth;
+  const float cull_c2 = pp->cull_c2, cull_kappa = pp->cull_kappa;
   const float rlx = pp->root_lo[0], rly = pp->root_lo[1], rlz = pp->root_lo[2];
   const float rhx = pp->root_hi[0], rhy = pp->root_hi[1], rhz = pp->root_hi[2];
   auto key_ptr = reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(key_lds);
@@ -425,6 +432,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
   for (;;) {   // one ray of the pixel's chain per iteration
     ray_derive(r);
     unsigned long long key = kKeyInit;
+    const float w2 = CULL ? cull_weight(r, cull_c2) : 0.0f;
     if (box_hit(r, rlx, rly, rlz, rhx, rhy, rhz)) {   // (uniform: every lane holds the same ray)
       if (lane == 0) {
         *key_ptr = kKeyInit;
@@ -473,8 +481,11 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
           }
           const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);
           const unsigned ml = (unsigned)f2i(q2.w), mr = (unsigned)f2i(q3.w);
-          const unsigned long long m_hl = bal(box_hit(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
-          const unsigned long long m_hr = bal(box_hit(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+          // (CULL: the boxes are tested against the ray's best root so far -- the key's high word -- instead of 1e9: lane_core.h, cull_limit.
+          // A node of the treelet that fails only against the limit is not reached, and neither is anything below it)
+          const float limc = CULL ? cull_limit(__uint_as_float(lds_load4(key_lds + 4u)), w2, cull_kappa) : kTMax;
+          const unsigned long long m_hl = bal(box_hit_clamped(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, limc));
+          const unsigned long long m_hr = bal(box_hit_clamped(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, limc));
           const bool reach = has && tl_reached(ml, mr, pos, (unsigned)(m_hl >> gsh), (unsigned)(m_hr >> gsh));
           const unsigned long long m_reach = bal(reach), m_exit = m_reach & bal(tl_frontier(ml));
           const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
@@ -547,10 +558,14 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // per ticket.  A tile's 64 pixels mix one or two long chains with dozens of short ones, so a wave that holds a deep TILE parks most of
 // its slots, and one that does not walks the long chain at a full wave's cadence; a ticket of pixels with EQUAL chain lengths keeps
 // its wave exactly as full as the chain's deadline allows, and the last tickets of the queue are all one-ray pixels (no drain).
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false>
+// CULL: boxes are tested against the slot's best root so far instead of the fixed 1e9 (lane_core.h: cull_limit) -- a
+// subtree whose every root is proven larger than a root already found is not walked.  Same pixels (the fold's RESULT is the contract,
+// ray.fut:76-86), fewer tests: irreg 1000 x 1000 -15 % box tests, -36 % sphere tests in this kernel's order (tools/cull_pooled.cpp).
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
   static_assert(!ORD || TAIL == 0, "ORD: no tail variant");
+  static_assert(!CULL || !ALL_LDS, "CULL: instantiated for the general scene path only");
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -677,7 +692,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
         Ray pr;
         primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
-        solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+        solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
                    pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, (lrow >> 3) * p.tiles_x + (col >> 3));
       }
     }
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
         Ray pr;
         primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
-        solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+        solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
                    pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, tile);
       }
     }
@@ -954,7 +969,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 const int src = uni((int)__builtin_ctzll(m_l));
                 m_l &= m_l - 1ull;
                 auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-                solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
+                solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
                            rl(r.oz), rl(r.dx), rl(r.dy), rl(r.dz), rl(lr), rl(lg), rl(lb), __builtin_amdgcn_readlane(pix, src),
                            __builtin_amdgcn_readlane(depth, src), __builtin_amdgcn_readlane(ptile, src));
               }
@@ -1005,7 +1020,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             wkey[lane] = kKeyInit;
             wcnt[lane] = root_hit ? 1 : 0;    // 0: the fold is already complete (a miss), shaded next time
             wray[lane] = make_float4(r.ox, r.oy, r.oz, r.a);
-            wray[64 + lane] = make_float4(r.ix, r.iy, r.iz, 0.0f);
+            wray[64 + lane] = make_float4(r.ix, r.iy, r.iz, CULL ? cull_weight(r, p.cull_c2) : 0.0f);   // (CULL: the ray's W2)
             if (p.ray_planes == 3) wray[128 + lane] = make_float4(r.dx, r.dy, r.dz, 0.0f);
             if (STATS) { n_rays++; n_box++; }
           }
@@ -1101,9 +1116,13 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         }
         asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w));   // 16-byte reads throughout
         const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);   // child references, stored pre-shifted by 8 (sign = leaf)
+        // (CULL: the interval's upper end is the slot's best root so far -- the high word of its hit key, one ds_read_b32 -- widened by
+        // the proven margin; the ray's weight W2 travels in the spare dword of the {1/d} entry.  Two v_fma + one v_min per item.)
+        float limc = kTMax;
+        if constexpr (CULL) limc = cull_limit(__uint_as_float(*reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(wkey) + 2 * sl4 + 4)), ri.w, p.cull_kappa);
         // lane masks straight from the compares; the rest is 64-bit scalar logic
-        const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
-        const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+        const unsigned long long m_hl = bal(box_hit_clamped(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, limc));
+        const unsigned long long m_hr = bal(box_hit_clamped(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, limc));
         const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
         // an inner child continues iff its box passes; a leaf child is tested because this node passed
         const unsigned long long m_inl = m_act & ~m_ln & m_hl, m_inr = m_act & ~m_rn & m_hr;
@@ -1165,8 +1184,10 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
             ref = f2i(buf_load16(rs_nodes, ni16 * 4 + 16 * role).w);
           }
         }
+        float limc = kTMax;
+        if constexpr (CULL) limc = cull_limit(__uint_as_float(*reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(wkey) + 2 * sl4 + 4)), ri.w, p.cull_kappa);
         const bool child_leaf = act & (ref < 0);
-        const bool pass = act & (ref >= 0) && box_hit(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+        const bool pass = act & (ref >= 0) && box_hit_clamped(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, limc);
         if (STATS) n_box += (act & (ref >= 0)) ? 1 : 0;
         // second level: the child's own record (a virtual item `ref | sl4`)
         const int ci16 = pass ? (int)(((unsigned)ref >> 4) & 0xfffffff0u) : 0;
@@ -1185,8 +1206,8 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         asm volatile("" ::"v"(q2.w), "v"(q3.w), "v"(ra.w), "v"(ri.w), "v"(lo.w), "v"(hi.w));
         const int cl8 = f2i(q0.w), cr8 = f2i(q1.w);
         const unsigned long long m_pass = bal(pass), m_cleaf = bal(child_leaf);
-        const unsigned long long m_hl = bal(box_hit(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z));
-        const unsigned long long m_hr = bal(box_hit(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z));
+        const unsigned long long m_hl = bal(box_hit_clamped(q, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, limc));
+        const unsigned long long m_hr = bal(box_hit_clamped(q, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, limc));
         const unsigned long long m_ln = bal(cl8 < 0), m_rn = bal(cr8 < 0);
         const unsigned long long m_inl = m_pass & ~m_ln & m_hl, m_inr = m_pass & ~m_rn & m_hr;
         // leaf appends: the child itself (lanes whose child is a leaf), or its leaf children -- never both for one lane
@@ -1245,7 +1266,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           if (lane == 0) __hip_atomic_store(&wbase[195], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           offered = false;
           __builtin_amdgcn_s_setprio(2);      // (a ray that arrives here is one of the workgroup's last)
-          solo_trace((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, a.x, a.y, a.z, a.w,
+          solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, a.x, a.y, a.z, a.w,
                      b.x, b.y, b.z, b.w, c.x, __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
           __builtin_amdgcn_s_setprio(0);
           continue;
@@ -1683,37 +1704,49 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0, bool ORD = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0, bool ORD = false, bool CULL = false>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL, ORD>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL, ORD, CULL>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
 }
 
+// The workgroups of 16 waves: every flavour, with and without CULL (a CULL launch always takes the general scene path: ALL_LDS is
+// an instantiation of the un-culled kernel only).
+template <bool STATS, bool SOLO, int TAIL, bool ORD>
+static hipError_t launch_pooled_16(const KParams &p, bool all_lds, int grid, hipStream_t stream) {
+  if (p.cull) return launch_pooled_t<1024, false, STATS, SOLO, TAIL, ORD, true>(p, grid, stream);
+  if constexpr (!STATS)
+    if (all_lds) return launch_pooled_t<1024, true, STATS, SOLO, TAIL, ORD>(p, grid, stream);
+  return launch_pooled_t<1024, false, STATS, SOLO, TAIL, ORD>(p, grid, stream);
+}
+
+// (p.cull is honoured by the workgroups of 16 waves -- what every scene within the pooled kernel's limits runs with unless an option
+// says otherwise; api.cpp clears it for the other shapes)
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
+  if (p.cull && waves_per_wg != 16) return hipErrorInvalidValue;
   if (stats && p.px_hdr != nullptr && waves_per_wg == 16)   // (the instrumented launch of a view that renders through its pixel list)
-    return p.solo ? launch_pooled_t<1024, false, true, true, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, true, false, 0, true>(p, grid, stream);
-  if (stats) return waves_per_wg == 16 ? launch_pooled_t<1024, false, true>(p, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
+    return p.solo ? launch_pooled_16<true, true, 0, true>(p, all_lds, grid, stream) : launch_pooled_16<true, false, 0, true>(p, all_lds, grid, stream);
+  if (stats) return waves_per_wg == 16 ? launch_pooled_16<true, false, 0, false>(p, all_lds, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
   // (SOLO: the instantiation with the solo prologue, for launches whose first tickets are single pixels)
   const bool solo = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == kTreeletDepth;
   // (ORD: pixel tickets; workgroups of 16 waves only)
   if (p.px_hdr != nullptr) {
     if (waves_per_wg != 16 || p.nframes != 1) return hipErrorInvalidValue;
-    if (!p.solo)   // (a list without a one-pixel class)
-      return all_lds ? launch_pooled_t<1024, true, false, false, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 0, true>(p, grid, stream);
-    return all_lds ? launch_pooled_t<1024, true, false, true, 0, true>(p, grid, stream) : launch_pooled_t<1024, false, false, true, 0, true>(p, grid, stream);
+    // (p.solo clear: a list without a one-pixel class)
+    return p.solo ? launch_pooled_16<false, true, 0, true>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 0, true>(p, all_lds, grid, stream);
   }
-  // (COLD: the first frame of a view; workgroups of 16 waves only -- other shapes render it with the ordinary kernels)
+  // (COLD: small ordered single frames; DONATE: the first frame of a view; workgroups of 16 waves only -- other shapes render them with the ordinary kernels)
   if (p.cold && waves_per_wg == 16)
-    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, 1>(p, grid, stream) : launch_pooled_t<1024, true, false, false, 1>(p, grid, stream))
-                   : (solo ? launch_pooled_t<1024, false, false, true, 1>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 1>(p, grid, stream));
+    return solo ? launch_pooled_16<false, true, 1, false>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 1, false>(p, all_lds, grid, stream);
   if (p.donate && waves_per_wg == 16)
-    return all_lds ? (solo ? launch_pooled_t<1024, true, false, true, 2>(p, grid, stream) : launch_pooled_t<1024, true, false, false, 2>(p, grid, stream))
-                   : (solo ? launch_pooled_t<1024, false, false, true, 2>(p, grid, stream) : launch_pooled_t<1024, false, false, false, 2>(p, grid, stream));
+    return solo ? launch_pooled_16<false, true, 2, false>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 2, false>(p, all_lds, grid, stream);
+  if (waves_per_wg == 16)
+    return solo ? launch_pooled_16<false, true, 0, false>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 0, false>(p, all_lds, grid, stream);
 #define RT_POOLED_CASE(W)                                                                                               \
   case W:                                                                                                               \
     return all_lds ? (solo ? launch_pooled_t<64 * W, true, false, true>(p, grid, stream) : launch_pooled_t<64 * W, true, false>(p, grid, stream)) \
@@ -1722,7 +1755,6 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
     RT_POOLED_CASE(4)
     RT_POOLED_CASE(8)
     RT_POOLED_CASE(12)
-    RT_POOLED_CASE(16)
   default: return hipErrorInvalidValue;
   }
 #undef RT_POOLED_CASE
@@ -1749,6 +1781,15 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, true>);
+  // ... and their CULL flavours
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 1, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 1, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, true, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, true, true>);
   (void)hipFuncGetAttributes(&a, (const void *)px_count_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_scan_kernel);
   (void)hipFuncGetAttributes(&a, (const void *)px_place_kernel);

@@ -254,6 +254,9 @@ struct KParams {
   const unsigned *px_list;   // ... and the list itself: (local row << 16) | column, longest bounce chains first
   int px_hold;           // bit k: a wave that draws a ticket of class k does not refill until it is finished
   int px_prio;           // ... and runs at this issue priority meanwhile (0 .. 3)
+  int cull;              // pooled family, workgroups of 16 waves: != 0 = the CULL instantiations (boxes are tested against the slot's best root so far: lane_core.h, cull_limit) ...
+  float cull_c2;         // ... the scene's constant in a ray's weight W2 = max|1 / d_k| * (d.d) * c2 ...
+  float cull_kappa;      // ... and in the limit best + W2 (best^2 + kappa)   (api.cpp: the prepared scene's CullConst)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
 };

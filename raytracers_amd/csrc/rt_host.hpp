@@ -89,6 +89,23 @@ struct TravLayout {
 };
 TravLayout make_trav_layout(const Lbvh &b, int treelet_depth = 1);
 
+// ---- culling by the best hit so far (lane_core.h: cull_limit) ----
+// The scene's side of the proof: whether its rays may be culled at all, and the two constants of the limit
+// best + W2 (best^2 + kappa), W2 = max|1 / d_k| * (d.d) * c2.  `ok` needs
+//   * every box to contain the boxes of the spheres below it: tree height <= the reference's floor(log2 n) + 2 sweeps
+//     (bvh.fut:47 -- a taller tree keeps unconverged upper boxes, which are the reference's answer and may not contain their subtree);
+//   * finite spheres with 2^-20 <= radius, |coordinate| + radius <= 2^40;
+//   * the scene guard: 2 (R + r_max) <= 2^15 r_min, R the half diagonal of the centres' box -- it keeps a root's error (E1) small
+//     against the sphere that produced it, which is what bounds a ray's distance to a sphere by its best root.
+// A launch additionally needs its camera inside the same guard (cull_origin_ok).
+struct CullConst {
+  bool ok = false;
+  float c2 = 0.0f, kappa = 0.0f;
+  double centre[3] = {0, 0, 0}, reach = 0.0, r_min = 0.0;   // centre of the centres' box; R + r_max
+};
+CullConst cull_scene_constants(const std::vector<Sphere> &ts, int height);
+bool cull_origin_ok(const CullConst &c, const float origin[3]);   // |origin - centre| + R + r_max <= 2^15 r_min
+
 // rows owned by part p of nparts under the cyclic row-tile partition
 int64_t part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts);
 

@@ -16,7 +16,13 @@
 struct rt_group;   // multi_gpu.cpp: the devices behind a multi-device context
 
 // ------------------------------------------------------------------------------------
+// Concurrency (SURVEY.md 8b "Async / threading": a Futhark context serialises concurrent calls with an internal lock): every entry
+// of the C ABI that takes a context holds the context's lock for the duration of the call -- host threads may share a context, a
+// prepared scene and a scene freely; their calls are serialised, their frames are enqueued on the context's one stream in the
+// order the calls were admitted.  Lock order: futhark_context -> rt_context (a multi-device parent before its children) ->
+// rt_prepared -> rt_scene.  The locks are recursive: entries call one another.
 struct rt_context {
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -62,6 +68,8 @@ struct rt_context {
   int px_zip = 1;           // ... the bulk's tickets alternately from the long and from the short end of its segment (0: sorted straight through)
   int px_prio = 3;          // ... at this issue priority (s_setprio 0 .. 3)
   int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
+  int cull = -1;            // pooled family, workgroups of 16 waves: the CULL instantiations -- boxes tested against the slot's best root so far (lane_core.h: cull_limit; same pixels, fewer tests).  -1 (auto): where the scene and the camera pass the proof's guards (rt_host.hpp: CullConst) and the scene is not wholly LDS resident (rgbbox-sized scenes: the walk is short, the tests saved do not pay for the limit's three instructions per item); 1: wherever the guards pass; 0: never
+  int sync_policy = 0;      // 1: a render entry WAITS for the view's class table (deep_policy) instead of polling for it -- which instantiation renders frame k is then the same in every run (measurements, PMC passes); 0: no render entry ever waits for the device
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
   // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
   unsigned *queue_dev = nullptr;
@@ -111,6 +119,8 @@ struct rt_scene {
   };
   mutable std::mutex mu;                 // a multi-device prepare_scene uploads from several host threads
   mutable std::vector<DevCopy> copies;
+  mutable bool cull_done = false;        // the spheres' side of the culling guards (rt_host.hpp: CullConst), computed by the first prepare_scene
+  mutable rt::CullConst cull;
 };
 
 // Tile-order state of one (image size, partition, depth, camera) view of a prepared scene.
@@ -143,6 +153,7 @@ struct TileOrder {
 constexpr int kClassSlotInts = 16, kClassSlots = 8;   // per prepared scene: one pinned slot per kept view
 
 struct rt_prepared {
+  mutable std::recursive_mutex mu;   // the views' orders are state of the prepared scene that render entries update: held while a frame is set up
   mutable std::vector<TileOrder> orders;
   mutable uint64_t order_clock = 0;
   int64_t n = 0;
@@ -150,6 +161,7 @@ struct rt_prepared {
   rt::Camera cam{};
   int height = 0;   // tree height
   int tl_depth = 1; // levels per treelet of the traversal copy (1: no treelets)
+  rt::CullConst cull;   // may this scene's rays be culled by their best hit, and with which constants (ok == false: never)
   // canonical {L, I} on the device (SoA, as bvh.fut:28 lays them out)
   float *L7 = nullptr, *bmin = nullptr, *bmax = nullptr;
   int32_t *left = nullptr, *right = nullptr, *parent = nullptr;
@@ -191,6 +203,16 @@ int group_set_variant(rt_context *ctx, int variant);
 int group_set_option(rt_context *ctx, const char *name, int64_t value);
 void group_destroy(rt_context *ctx);
 }  // namespace rti
+
+// first statement of every C-ABI entry that takes a context (a null context is refused by the entry's own checks)
+// (-DRT_NO_CONTEXT_LOCK: the locks compiled out -- only for build/tsan_nolock, the run that shows what the thread sanitizer reports without them)
+#ifndef RT_NO_CONTEXT_LOCK
+#define RT_LOCK(ctx) std::unique_lock<std::recursive_mutex> rt_lock_ = (ctx) ? std::unique_lock<std::recursive_mutex>((ctx)->mu) : std::unique_lock<std::recursive_mutex>()
+#define RT_LOCK_PS(ps) std::lock_guard<std::recursive_mutex> ps_lock_((ps)->mu)
+#else
+#define RT_LOCK(ctx) (void)(ctx)
+#define RT_LOCK_PS(ps) (void)(ps)
+#endif
 
 #define RT_HIP(ctx, call)                                             \
   do {                                                                \

@@ -121,12 +121,13 @@ class OracleScene:
         cam = self.camera(h, w)
         return np.frombuffer(bytes(cam), dtype=np.float32).copy()
 
-    def render(self, h, w, max_depth=50, threads=0, rows=None):
-        """Returns (pixels[h_band, w] int32, counters dict)."""
+    def render(self, h, w, max_depth=50, threads=0, rows=None, cam=None):
+        """Returns (pixels[h_band, w] int32, counters dict).  cam: 12 floats {origin, llc, horizontal, vertical} instead of the
+        camera prepare_scene derives (ray.fut:241-244)."""
         r0, r1 = (0, h) if rows is None else rows
         out = np.empty((r1 - r0, w), dtype=np.int32)
         cnt = Counters()
-        cam = self.camera(h, w)
+        cam = self.camera(h, w) if cam is None else Camera.from_buffer_copy(np.ascontiguousarray(cam, dtype=np.float32).tobytes())
         rc = lib().orc_render_rows(C.byref(self.bvh), C.byref(cam), w, h, r0, r1, max_depth, threads,
                                    out.ctypes.data, C.byref(cnt))
         assert rc == 0

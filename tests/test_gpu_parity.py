@@ -311,6 +311,92 @@ def test_pixel_tickets(R, opts):
     c.close()
 
 
+@pytest.mark.parametrize("opts", [dict(cull=1), dict(cull=-1), dict(cull=0), dict(cull=1, pixel_order=2), dict(cull=1, pixel_order=0), dict(cull=1, pixel_order=0, deep_class=8, deep_split=6, deep_cap_log2=0),
+                                  dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8), dict(cull=1, solo=0), dict(cull=1, lds_scene_bytes=0),
+                                  dict(cull=1, gpu_build=0), dict(cull=1, look_max=1, thr_shade=64)])
+def test_cull_by_best_hit(R, opts):
+    """The CULL instantiations of the pooled kernel (lane_core.h: cull_limit): boxes are tested against the slot's best
+    root so far, widened by a proven margin, instead of the reference's fixed 1e9 (ray.fut:77) -- fewer tests, the SAME fold result
+    (ray.fut:76-86).  Every flavour (plain, SOLO, COLD, DONATE, ORD; BOX, BOX2 and the solo loop's treelet operation), frames 1 .. 4 of a
+    view, a part packed and in place, batches with and without their own cameras; scenes: the reference's, floors, random spheres with
+    radii 0.5 .. 6 and coincident centres, a single inner node.  Where the proof's guards do NOT hold the library must fall back by
+    itself: a 36-level tree (unconverged boxes: height > sweeps), a camera 10^6 radii away; rt_context_last_launch says which ran."""
+    import torch
+    from raytracers_amd.dist import tile_rows
+    c = R.Context()
+    c.set_variant(3)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    cases = _solo_cases() + [("irreg", None, 500, 500), ("floor:12:72", None, 64, 64)]
+    for name, custom, h, w in cases:
+        if custom is None:
+            orc, sc = _oracle(name), _scene(c, name)
+        else:
+            orc = O.OracleScene("custom", spheres7=custom[0], look_from=custom[1], look_at=custom[2], fov=custom[3])
+            sc = c.scene_from_spheres(*custom)
+        want, _ = orc.render(h, w)
+        ps = R.prepare_scene(h, w, sc)
+        tall = custom is not None and len(custom[0]) == 95       # the 36-level tree: never culled
+        whole_lds = name in ("rgbbox", "floor:37:222", "floor:12:72") or (custom is not None and len(custom[0]) <= 700)
+        out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        for frame in range(4):
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(out.data_ptr(), h, w, ps)
+            c.sync()
+            assert int((out.cpu().numpy() != want).sum()) == 0, (name, frame, c.last_launch)
+            culled = "+CULL" in c.last_launch
+            if opts["cull"] == 0 or tall or name == "rgbbox":    # (rgbbox: height 14 > 10 sweeps)
+                assert not culled, (name, c.last_launch)
+            elif opts["cull"] == 1 and "waves=16" in c.last_launch:
+                assert culled, (name, c.last_launch)
+            elif opts["cull"] == -1 and "waves=16" in c.last_launch and "lds_scene_bytes" not in opts:
+                assert culled == (not whole_lds), (name, c.last_launch)
+        rows = R.part_rows(h, 1, 3)
+        part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
+        for frame in range(3):
+            part.fill_(-3)
+            torch.cuda.synchronize()
+            R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
+            c.sync()
+            assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, "part", frame)
+        image = torch.full((h, w), -5, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for frame in range(2):
+            R.render_inplace_into(image.data_ptr(), h, w, ps, part=1, nparts=3)
+        c.sync()
+        got = image.cpu().numpy()
+        mine = np.zeros(h, bool)
+        mine[tile_rows(h, 1, 3)] = True
+        assert int((got[mine] != want[mine]).sum()) == 0 and bool((got[~mine] == -5).all()), (name, "in place")
+        buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+        c.sync()
+        assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch")
+        if opts["cull"] == 1 and not tall and name != "rgbbox" and "waves=16" in c.last_launch:
+            assert "+CULL" in c.last_launch, (name, c.last_launch)
+        # a batch with its own cameras: the prepared one, one a little off, and one far outside the scene guard (the whole batch then
+        # renders un-culled: every origin must pass)
+        cam = ps.camera()
+        near = cam.copy(); near[0:3] += np.float32(0.5); near[3:6] += np.float32(0.5)     # origin and lower-left corner move together
+        far = cam.copy(); far[0:3] += np.float32(4.0e6); far[3:6] += np.float32(4.0e6)
+        for cams, label in ((np.stack([cam, near, cam]), "cams near"), (np.stack([cam, far, near]), "cams far")):
+            buf.fill_(-7)
+            torch.cuda.synchronize()
+            R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w, cams=cams)
+            c.sync()
+            ll = c.last_launch
+            frames = buf.cpu().numpy()
+            for f in range(3):
+                wf, _ = orc.render(h, w, cam=cams[f])
+                assert int((frames[f] != wf).sum()) == 0, (name, label, f, ll)
+            if label == "cams far":
+                assert "+CULL" not in ll, (name, ll)
+        ps.free()
+    c.close()
+
+
 @pytest.mark.parametrize("opts", [dict(), dict(handover=0), dict(thr_shade=8), dict(gpu_build=0), dict(box2=0), dict(static_first=0),
                                   dict(xcd_queues=0, thr_shade=64), dict(handover=2, donate_max=1), dict(handover=2, donate_max=64),
                                   dict(handover=2, donate_max=8, thr_shade=8), dict(handover=2, donate_max=64, grid_div=4)])
@@ -730,17 +816,49 @@ def test_wave_trace_of_the_instrumented_launch(R, scene, h, w):
     want, cnt = _oracle(scene).render(h, w)
     for _ in range(2):   # recording frame, ordered frame
         assert int((R.render(h, w, ps) != want).sum()) == 0
-    rec = np.zeros((8192, 16), dtype=np.uint64)
-    n = C.c_int32()
-    c._check(lib.rt_render_trace(c._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
-    assert 0 < n.value <= 8192
-    rec = rec[: n.value].astype(np.int64)
-    assert (rec[:, 0] > 0).all() and (rec[:, 2] >= rec[:, 0]).all()            # start / end wall clock
-    assert int((rec[:, 6] & 0xFFFFFFFF).sum()) == cnt["leaf_tests"]              # leaf items == sphere tests
-    ops = (rec[:, 3] & 0x1FFFFF) + ((rec[:, 3] >> 21) & 0x1FFFFF) + ((rec[:, 3] >> 42) & 0x1FFFFF)
-    assert int(ops.sum()) > 0 and int((rec[:, 7] & 0xFFFF).max()) >= 1          # operations ran, a bounce chain was seen
-    assert int((R.render(h, w, ps) != want).sum()) == 0
+    # (cull = 0: the reference's full test set; cull = 1: the same fold with subtrees behind the best hit left out -- irreg only: rgbbox's
+    # tree is taller than its sweeps, its upper boxes are unconverged and it is never culled)
+    for cull in (0, 1):
+        c.set_option("cull", cull)
+        rec = np.zeros((8192, 16), dtype=np.uint64)
+        n = C.c_int32()
+        c._check(lib.rt_render_trace(c._h, ps._h, h, w, 50, rec.ctypes.data, 8192, C.byref(n)))
+        assert 0 < n.value <= 8192
+        rec = rec[: n.value].astype(np.int64)
+        assert (rec[:, 0] > 0).all() and (rec[:, 2] >= rec[:, 0]).all()            # start / end wall clock
+        leaf_items = int((rec[:, 6] & 0xFFFFFFFF).sum())
+        if cull == 0 or scene == "rgbbox":
+            assert leaf_items == cnt["leaf_tests"]                                   # leaf items == sphere tests
+        else:
+            assert 0 < leaf_items < cnt["leaf_tests"] * 0.9                          # culled: fewer sphere tests (-36 % at 1000 x 1000)
+        ops = (rec[:, 3] & 0x1FFFFF) + ((rec[:, 3] >> 21) & 0x1FFFFF) + ((rec[:, 3] >> 42) & 0x1FFFFF)
+        assert int(ops.sum()) > 0 and int((rec[:, 7] & 0xFFFF).max()) >= 1          # operations ran, a bounce chain was seen
+        assert int((R.render(h, w, ps) != want).sum()) == 0
     c.close()
+
+
+# ---------------------------------------------------------------- threads sharing a context ----
+@pytest.mark.parametrize("mode,scene", [("rt", "irreg"), ("rt", "rgbbox"), ("futhark", "irreg")])
+def test_host_threads_share_one_context(mode, scene):
+    """a Futhark context serialises concurrent calls with an internal lock.  tools/ctx_threads: two host threads, ONE
+    context, ONE prepared scene (mode rt: a view each -- both views' orders and pixel lists live in the one rt_prepared; mode futhark: a
+    prepared scene each on one futhark_context, images through its pool), 200 frames each with render + sync + values per frame
+    and option writes in between.  Every frame must equal its view's first, and the views' checksums the CPU checker's.
+    (The same program over a -fsanitize=thread build of the library's host code: tools/gpu.sh tsan, log under profiles/r06/.)"""
+    exe = os.path.join(ROOT, "build", "ctx_threads")
+    subprocess.run(["make", "-s", "build/ctx_threads"], cwd=ROOT, check=True)
+    n, frames, threads = 256, 200, 2
+    out = subprocess.run([exe, mode, scene, str(n), str(frames), str(threads)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "every frame equals its view's first" in out.stdout, out.stdout + out.stderr
+    orc = _oracle(scene)
+    for k in range(threads):
+        if mode == "rt":
+            cam = orc.camera_floats(n, n)
+            cam[0] += np.float32(0.37) * np.float32(k)
+            want, _ = orc.render(n, n, cam=cam)
+        else:
+            want, _ = orc.render(n + 8 * k, n)
+        assert f"thread {k} checksum {O.checksum(want):08x}" in out.stdout, (k, out.stdout)
 
 
 # ---------------------------------------------------------------- row-tile partition ------

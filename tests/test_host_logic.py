@@ -148,6 +148,44 @@ def test_treelet_numbering_and_masks_on_the_cpu(scene, size):
     assert out.stdout.count("same leaf sets from the records") == 4
 
 
+def test_cull_limit_is_conservative_on_the_cpu():
+    """tools/cull_bound_check hammers the two inequalities the CULL instantiations rest on (lane_core.h: cull_limit)
+    with the product's own binary32 code against __float128: (E1) a computed root lies within 2^-18 (D^2 + r^2) of the sphere,
+    (S) a sphere's own box is never culled by the limit computed from that sphere's own root -- random and adversarial pairs
+    (grazing, far, nearly axis-parallel, origin inside the sphere).  With the margin scaled down 1000 x the checker must FIND
+    violations: it is not vacuous."""
+    exe = os.path.join(ROOT, "build", "cull_bound_check")
+    subprocess.run(["make", "-s", "build/cull_bound_check"], cwd=ROOT, check=True)
+    for seed in (1, 2):
+        out = subprocess.run([exe, "12", str(seed)], capture_output=True, text=True)
+        assert out.returncode == 0 and "E1 violations 0 " in out.stdout and "safety violations 0" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([exe, "12", "1", "0.001"], capture_output=True, text=True)
+    assert out.returncode != 0 and "safety violations 0" not in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("scene,h,w", [("irreg", 120, 160), ("floor:40:240", 96, 96), ("rgbbox", 96, 96)])
+def test_culled_pooled_loop_keeps_the_pixels_on_the_cpu(scene, h, w):
+    """tools/cull_pooled plays the pooled kernel's loop (shared LIFO, deferred sphere tests, refill in place) on emulated lanes,
+    without and with the product's culling rule: same checksum as the oracle, never more tests."""
+    exe = os.path.join(ROOT, "build", "cull_pooled")
+    subprocess.run(["make", "-s", "build/cull_pooled"], cwd=ROOT, check=True)
+    out = subprocess.run([exe, scene, str(h), str(w), "64", "0", "0", "0", "40", "32", "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if scene.startswith("floor"):
+        _, n, k = scene.split(":")
+        sc = O.OracleScene("floor", n=int(n), k=float(k))
+    else:
+        sc = O.OracleScene(scene)
+    px, cnt = sc.render(h, w)
+    modes = [l for l in out.stdout.splitlines() if l.startswith("mode ")]
+    assert len(modes) == 2
+    got = [dict(re.findall(r"(checksum|diff|rays|box|sphere) ([0-9a-f]+)", l)) for l in modes]
+    for g in got:
+        assert g["checksum"] == "%08x" % O.checksum(px) and g["diff"] == "0" and int(g["rays"]) == cnt["rays"]
+    assert int(got[0]["box"]) == cnt["box_tests"] and int(got[0]["sphere"]) == cnt["leaf_tests"]
+    assert int(got[1]["box"]) <= cnt["box_tests"] and int(got[1]["sphere"]) <= cnt["leaf_tests"]
+
+
 def test_reference_harness_builds_against_our_header():
     """/root/reference/futhark/main.c must compile and link unmodified (build container only)."""
     if not os.path.exists("/root/reference/futhark/main.c"):

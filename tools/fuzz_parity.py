@@ -15,7 +15,7 @@ max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 160
 max_n = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
 ctx = R.Context()
 t_end = time.time() + budget
-cases = fails = 0
+cases = fails = culled_launches = 0
 while time.time() < t_end:
     seed = seed0 + cases
     rng = np.random.default_rng(seed)
@@ -76,7 +76,9 @@ while time.time() < t_end:
                  px_solo_div=int(rng.choice([1, 4, 64, 4096])),
                  # ... and the constants of the model that cuts the classes when px_solo is 0 (bounce cadences in 0.1 us, ns per ray)
                  px_g1=int(rng.choice([0, 1, 25, 1000])), px_g8=int(rng.choice([0, 3, 45])), px_g16=int(rng.choice([0, 5, 65])),
-                 px_g32=int(rng.choice([0, 7, 100])), px_g64=int(rng.choice([0, 9, 160, 5000])), px_ray_ns=int(rng.choice([0, 1, 300, 20000])))
+                 px_g32=int(rng.choice([0, 7, 100])), px_g64=int(rng.choice([0, 9, 160, 5000])), px_ray_ns=int(rng.choice([0, 1, 300, 20000])),
+                 # culling by the best hit so far (the CULL instantiations): off / where the library would / wherever the proof's guards hold
+                 cull=int(rng.choice([0, -1, 1, 1, 1])))
     for kv in os.environ.get("FUZZ_FORCE", "").split(","):     # e.g. FUZZ_FORCE=handover=2,donate_max=8: knobs pinned for an experiment
         if kv:
             knobs[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -93,7 +95,9 @@ while time.time() < t_end:
         for variant in ((3, 1, 2) if gpu_build else (3,)):
             ctx.set_variant(variant)
             px = R.render(h, w, ps, max_depth=md)
+            culled_launches += "+CULL" in ctx.last_launch
             px2 = R.render(h, w, ps, max_depth=md)      # second frame: adaptive tile order / deep tiles
+            culled_launches += "+CULL" in ctx.last_launch
             ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
             if variant == 3:                            # third frame: the ticket counter after a frame with deep-tile pieces
                 ok &= int((R.render(h, w, ps, max_depth=md) != ref).sum()) == 0
@@ -135,5 +139,5 @@ while time.time() < t_end:
         fails += 1
         print(f"MISMATCH seed {seed}: n={n} kind={kind} ext={ext} {w}x{h} max_depth={md} knobs={knobs} nparts={nparts}", flush=True)
 ctx.set_option("gpu_build", 1)
-print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1})", flush=True)
+print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1}); {culled_launches} of the first / second frames ran a CULL instantiation", flush=True)
 sys.exit(1 if fails else 0)
