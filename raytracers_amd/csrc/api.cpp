@@ -308,7 +308,7 @@ int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves
 
 // Behind the tile-order sort of a view: its class table on its way to the host (stream-ordered copy into the view's pinned
 // slot + an event).  Nothing waits here.
-int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
+int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to, hipStream_t stream) {
   rt_prepared *ps = const_cast<rt_prepared *>(ps_c);   // (the orders are `mutable` state of a prepared scene; so is their landing area)
   to->classes_pending = false;
   if (ctx->deep_class >= 0 || to->nshards != 1) return 0;   // no policy reads the table
@@ -324,10 +324,71 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to) {
   }
   if (!to->classes_event) RT_HIP(ctx, hipEventCreateWithFlags(&to->classes_event, hipEventDisableTiming));
   RT_HIP(ctx, hipMemcpyAsync(ps->classes_pinned + kClassSlotInts * to->classes_slot, to->order + to->ntiles, sizeof to->classes,
-                             hipMemcpyDeviceToHost, ctx->stream));
-  RT_HIP(ctx, hipEventRecord(to->classes_event, ctx->stream));
+                             hipMemcpyDeviceToHost, stream));
+  RT_HIP(ctx, hipEventRecord(to->classes_event, stream));
   to->classes_pending = true;
   return 0;
+}
+
+// The sorts that turn a view's record (its last recording frame's cost / cost_px) into its tile order and pixel list, + the class table
+// on its way to the host.  eager_sort (the default): on the context's SECOND stream, behind an event of the main stream -- they run
+// while the caller synchronises and sets up its next call; whoever uses the order next makes the main stream wait for `sort_event`
+// (await_view).  Otherwise on the main stream, in line.  `p` / `pl`: the geometry and launch plan of a frame of this view (any frame of the
+// view has the same).
+int sort_view(rt_context *ctx, const rt_prepared *ps, TileOrder *v, const rtk::KParams &p, const Plan &pl) {
+  if (!v->sort_pending) return 0;
+  v->sort_pending = false;
+  hipStream_t st = ctx->stream;
+  if (ctx->eager_sort) {
+    if (!ctx->sort_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->sort_stream, hipStreamNonBlocking));
+    if (!ctx->rec_event) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->rec_event, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventRecord(ctx->rec_event, ctx->stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, ctx->rec_event, 0));
+    st = ctx->sort_stream;
+  }
+  if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
+  RT_HIP(ctx, rtk::launch_tile_order(v->cost, v->order, v->ntiles, p.tiles_x, v->nshards, ctx->order_scratch, st));
+  v->valid = true;
+  v->have_classes = false;
+  if (int rc = request_classes(ctx, ps, v, st)) return rc;
+  if (v->sort_px) {
+    // ... and the view's pixel list from the per-pixel record
+    if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
+    const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, v->rec_out_skip, p.tiles_x, p.tiles_y};
+    rtk::PxPolicy pol{};
+    for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
+    // the model's bounce cadences (0.1 us; measured, profiles/r05/README.md): a scene that lives in LDS, one that is read from L2
+    const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
+    static const int g_lds[5] = {25, 45, 65, 100, 180}, g_l2[5] = {45, 120, 170, 230, 330};   // (LDS: 64 rays 24 us sorted straight through, 18 with the bulk zipped: e14)
+    for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
+    pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
+    pol.nwaves = pl.grid_full * pl.waves;
+    // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel
+    // without the solo call is 1-5 % faster)
+    pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
+    v->px_solo = pol.solo_cap > 0;
+    pol.zip = ctx->px_zip;
+    RT_HIP(ctx, rtk::launch_px_order(v->cost_px, g, pol, v->px_list, reinterpret_cast<int *>(v->px_list + v->px_elems), ctx->px_scratch, st));
+    v->px_valid = true;
+  }
+  if (st != ctx->stream) {
+    if (!v->sort_event) RT_HIP(ctx, hipEventCreateWithFlags(&v->sort_event, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventRecord(v->sort_event, st));
+    v->sort_inflight = true;
+  }
+  return 0;
+}
+// the main stream waits for a view's sorts (once: everything behind the wait is ordered after them)
+int await_view(rt_context *ctx, TileOrder *v) {
+  if (!v->sort_inflight) return 0;
+  RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->sort_event, 0));
+  v->sort_inflight = false;
+  return 0;
+}
+// both streams drained (before buffers the sorts may touch are freed)
+void drain_streams(rt_context *ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->sort_stream) (void)hipStreamSynchronize(ctx->sort_stream);
 }
 
 // May this launch cull (lane_core.h: cull_limit)?  The scene's guards (rt_prepared::cull), the launch shape the CULL instantiations
@@ -466,20 +527,20 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
-    TileOrder *to = nullptr;
+    TileOrder *to = nullptr;      // the view this frame belongs to (its record, its order, its pixel list)
+    TileOrder *use = nullptr;     // the view whose order / pixel list this frame is rendered through: `to`, or the view it borrows from
+    bool borrowed = false;
     if (ctx->adaptive_order && !p.cams) {   // (a batch with its own cameras has no single view to order tiles by)
+      auto same_shape = [&](const TileOrder &o) {
+        return o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts && o.max_depth == max_depth &&
+               o.ntiles == p.nchunks && o.nshards == order_shards;
+      };
       for (auto &o : ps->orders)
-        if (o.h == h && o.w == w && o.rows_per_tile == rows_per_tile && o.part == part && o.nparts == nparts &&
-            o.max_depth == max_depth && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && o.ntiles == p.nchunks &&
-            o.nshards == order_shards)
-          to = &o;
+        if (same_shape(o) && std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0) to = &o;
       if (!to) {
         // A view not seen before: at most 8 are kept; the least recently used one gives up its buffers, which are reused as
         // they are when the sizes match (a camera path rendered frame by frame: stream-ordered, no synchronisation and no
         // hipFree / hipMalloc per new view).
-        // (Tried: the new view BORROWS the tile order of the view rendered last with the same geometry for its first frame.
-        // Measured useless on both scenes -- 0.64 / 0.63 ms per frame of a sliding camera against 0.68 / 0.74 without: which
-        // tiles hold this frame's longest chains is as chaotic as the chains themselves, profiles/r03/exp/e25.)
         TileOrder o{};
         // (pixel tickets: the per-pixel record and the pixel list of the view, if this context may use them)
         const bool px_ok = ctx->pixel_order != 0 && w < 65536 && p.rows_local < 65536 && (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
@@ -492,13 +553,15 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           TileOrder &v = ps->orders[lru];
           o.classes_event = v.classes_event;   // (a copy still in flight lands in the slot before any later one: same stream)
           o.classes_slot = v.classes_slot;
-          if (v.ntiles == p.nchunks && v.cost_px_bytes >= px_bytes && v.px_elems >= px_elems) {
+          o.sort_event = v.sort_event;
+          if (int rc = await_view(ctx, &v)) return rc;   // (sorts of the evicted view still running on the sort stream touch these buffers: the main stream goes behind them)
+          if (v.ntiles == p.nchunks && v.cost_px_bytes >= px_bytes && v.px_elems >= px_elems && (px_ok || !v.px_list)) {
             o.cost = v.cost;
             o.order = v.order;
             o.cost_px = v.cost_px; o.cost_px_bytes = v.cost_px_bytes;
             o.px_list = v.px_list; o.px_elems = v.px_elems;
           } else {
-            (void)hipStreamSynchronize(ctx->stream);
+            drain_streams(ctx);
             (void)hipFree(v.cost);
             (void)hipFree(v.order);
             (void)hipFree(v.cost_px);
@@ -525,49 +588,40 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         to = &ps->orders.back();
       }
       to->stamp = ++ps->order_clock;
-      if (to->sort_pending) {
-        // the view's last frame left a record: the next frames' ticket -> tile table from it (this also clears the record) ...
-        to->sort_pending = false;
-        if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
-        RT_HIP(ctx, rtk::launch_tile_order(to->cost, to->order, to->ntiles, p.tiles_x, to->nshards, ctx->order_scratch, ctx->stream));
-        to->valid = true;
-        to->have_classes = false;
-        if (int rc = request_classes(ctx, ps, to)) return rc;
-        if (to->sort_px) {
-          // ... and the view's pixel list from the per-pixel record
-          if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
-          const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, to->rec_out_skip, p.tiles_x, p.tiles_y};
-          rtk::PxPolicy pol{};
-          for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
-          // the model's bounce cadences (0.1 us; measured, profiles/r05/README.md): a scene that lives in LDS, one that is read from L2
-          const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-          static const int g_lds[5] = {25, 45, 65, 100, 180}, g_l2[5] = {45, 120, 170, 230, 330};   // (LDS: 64 rays 24 us sorted straight through, 18 with the bulk zipped: e14)
-          for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
-          pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
-          pol.nwaves = pl.grid_full * pl.waves;
-          // (no one-pixel class for a launch of more than 32 768 tiles: its work bounds it, not its longest chains -- and the kernel
-          // without the solo call is 1-5 % faster)
-          pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
-          to->px_solo = pol.solo_cap > 0;
-          pol.zip = ctx->px_zip;
-          RT_HIP(ctx, rtk::launch_px_order(to->cost_px, g, pol, to->px_list, reinterpret_cast<int *>(to->px_list + to->px_elems), ctx->px_scratch,
-                                           ctx->stream));
-          to->px_valid = true;
+      // the view's last frame left a record that nothing has sorted yet (eager_sort = 0, or a record made before the option was set)
+      if (int rc = sort_view(ctx, ps, to, p, pl)) return rc;
+      use = to->valid ? to : nullptr;
+      // A NEW view (no order of its own yet) borrows the order / pixel list of the most recently rendered view of the same shape
+      // (`borrow`): the reference's render is stateless (ray.fut:246) and a caller that moves the camera renders nothing but first
+      // frames -- which were unordered (tiles in bit-reversed order, DONATE tail).  Neighbouring views agree on WHERE the long chains
+      // are (they cluster at the walls' edges / at grazing angles, profiles/r04/README.md) even though single pixels do not; the
+      // chains the borrowed list places wrongly are what the DONATE tail catches.  Only the order of independent pixels changes.
+      if (!use && ctx->borrow && nframes == 1 && ctx->adaptive_order == 1) {
+        TileOrder *from = nullptr;
+        for (auto &o : ps->orders)
+          if (&o != to && same_shape(o) && (o.valid || o.sort_pending) && (!from || o.stamp > from->stamp)) from = &o;
+        if (from) {
+          if (int rc = sort_view(ctx, ps, from, p, pl)) return rc;
+          use = from;
         }
       }
+      if (use)
+        if (int rc = await_view(ctx, use)) return rc;
+      borrowed = use != nullptr && use != to;
       // The record of a view is a deterministic function of the view, so the table is computed
       // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
       // recomputes every frame (testing aid).
       // (a view whose tiles were first recorded by a batch has no per-pixel record yet: its first single frame records again)
       const bool px_can = ctx->pixel_order != 0 && nframes == 1 && to->px_list != nullptr && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-                          to->cost_px_bytes >= static_cast<size_t>(h) * w && (p.nshards == 1 || p.interleave) &&
+                          to->cost_px_bytes >= static_cast<size_t>(h) * w && w < 65536 && p.rows_local < 65536 && (p.nshards == 1 || p.interleave) &&
                           (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
       const bool rerecord = !to->valid || ctx->adaptive_order == 2 || (px_can && !to->px_valid);
       p.cost = rerecord ? to->cost : nullptr;
       p.cost_px = rerecord && px_can ? to->cost_px : nullptr;
-      p.order = to->valid ? to->order : nullptr;
+      p.order = use ? use->order : nullptr;
       DeepPolicy dp;
-      if (int rc = deep_policy(ctx, ps, nframes == 1 ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
+      if (int rc = deep_policy(ctx, ps, (nframes == 1 && !borrowed) ? to : nullptr, pl.grid_full * pl.waves, &dp)) return rc;
+      if (borrowed) dp = DeepPolicy{0, 0, ctx->deep_cap_log2, true};   // (a borrowed order: no tile holds its wave -- which tiles are deep is the other view's truth)
       // A view's FIRST frame (no order yet): every workgroup -- the half-size launch that serves a partly LDS-resident scene's
       // ordered frames best lets an unordered one wait for its late chains with half the chip (irreg, first frame: 700 x 700
       // 0.605 -> 0.545 ms, 1000 x 1000 0.714 -> 0.625, 1400 x 1400 0.909 -> 0.738; profiles/r04/exp/e7).
@@ -594,16 +648,16 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     // Pixel tickets (the ORD instantiation): an ordered single frame of a view that has its pixel list draws from it -- every
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
-    if (to && to->valid && to->px_valid && nframes == 1 && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 &&
-        (p.nshards == 1 || p.interleave) && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
+    if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 &&
+        (p.nshards == 1 || p.interleave) && use->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
         (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
                                    (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {
-      p.px_list = to->px_list;
-      p.px_hdr = reinterpret_cast<const int *>(to->px_list + to->px_elems);
+      p.px_list = use->px_list;
+      p.px_hdr = reinterpret_cast<const int *>(use->px_list + use->px_elems);
       p.px_hold = ctx->px_hold;
       p.px_prio = ctx->px_prio;
       p.cold = 0;
-      p.solo = (to->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
+      p.solo = (use->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
       if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
         const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
         const int il = ns > 1 && xq == 2;
@@ -617,8 +671,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     // 500 x 500 0.519 -> 0.373 ms, 1000 x 1000 0.588 -> 0.486, a rank's eighth of 4000 x 4000 0.83 / 0.92 -> 0.67 / 0.72, the
     // 10^6-sphere frame 1.74 -> 1.50, rgbbox 1000 x 1000 0.617 -> 0.549; ordered frames do not gain (within 1 % at every size)
     // and keep their kernels.  handover=2 (testing): every single frame, a wave offers its rays when it holds <= donate_max.
+    // (... and a frame rendered through a BORROWED order / pixel list: the long chains that list places wrongly start late too)
     if (nframes == 1 && max_depth > 4 && pl.waves == 16 && ctx->solo && ps->tl_depth == rtk::kTreeletDepth &&
-        (ctx->handover == 2 || (ctx->handover == 1 && p.order == nullptr))) {
+        (ctx->handover == 2 || (ctx->handover == 1 && (p.order == nullptr || borrowed)))) {
       p.cold = 0;
       p.donate = ctx->handover == 2 ? ctx->donate_max : 64;
     }
@@ -642,11 +697,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     {
       // (which instantiation launch_pooled picks, in its own order of precedence)
       const bool single_px = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == rtk::kTreeletDepth;
-      const char *inst = p.px_hdr ? (p.solo ? "ORD+SOLO" : "ORD") : (p.cold && pl.waves == 16) ? (single_px ? "COLD+SOLO" : "COLD")
+      const char *inst = p.px_hdr ? (p.donate ? (p.solo ? "ORD+SOLO+DONATE" : "ORD+DONATE") : (p.solo ? "ORD+SOLO" : "ORD")) : (p.cold && pl.waves == 16) ? (single_px ? "COLD+SOLO" : "COLD")
                          : (p.donate && pl.waves == 16) ? (single_px ? "DONATE+SOLO" : "DONATE") : (single_px ? "SOLO" : "plain");
       char buf[256];
-      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s instantiation=%s%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
-                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), inst, p.cull ? "+CULL" : "", p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
+      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s%s instantiation=%s%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
+                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), borrowed ? "(borrowed)" : "", inst, p.cull ? "+CULL" : "", p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
                     p.interleave ? "(turns)" : "", p.px_hdr ? 0 : p.deep_class, p.px_hdr ? 0 : p.deep_split, p.cost ? (p.cost_px ? 2 : 1) : 0);
       ctx->last_launch = buf;
     }
@@ -658,6 +713,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       to->sort_pending = true;
       to->sort_px = p.cost_px != nullptr;
       to->rec_out_skip = p.out_skip;
+      // (eager_sort, the default: ... but they are LAUNCHED here, on the context's second stream, behind this frame: they run while the caller
+      // synchronises and sets up its next call, off every frame's critical path -- the view's second frame no longer carries them, and a
+      // new view can borrow this one's order at once)
+      if (ctx->eager_sort)
+        if (int rc = sort_view(ctx, ps, to, p, pl)) return rc;
     }
   }
   else {
@@ -732,7 +792,9 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (!ctx) return;
   if (ctx->group) rti::group_destroy(ctx);
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  drain_streams(ctx);
+  if (ctx->sort_stream) (void)hipStreamDestroy(ctx->sort_stream);
+  if (ctx->rec_event) (void)hipEventDestroy(ctx->rec_event);
   for (auto &t : ctx->uv) {
     (void)hipFree(t.u);
     (void)hipFree(t.v);
@@ -883,6 +945,11 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->px_hold = v & 0x1f;
   } else if (k == "px_solo_div") {
     ctx->px_solo_div = std::max(1, std::min(4096, v));
+  } else if (k == "eager_sort") {
+    drain_streams(ctx);            // (sorts in flight on either stream finish under the setting they were launched with)
+    ctx->eager_sort = v != 0;
+  } else if (k == "borrow") {
+    ctx->borrow = v != 0;
   } else if (k == "cull") {
     ctx->cull = std::max(-1, std::min(1, v));
   } else if (k == "sync_policy") {
@@ -1086,7 +1153,7 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   if (!ps->replicas.empty()) rti::group_prepared_free(ctx, ps);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    drain_streams(ctx);
   }
   pool_free(ctx, ps->block, ps->block_bytes);
   for (auto &o : ps->orders) {
@@ -1095,6 +1162,7 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
     (void)hipFree(o.cost_px);
     (void)hipFree(o.px_list);
     if (o.classes_event) (void)hipEventDestroy(o.classes_event);
+    if (o.sort_event) (void)hipEventDestroy(o.sort_event);
   }
   if (ps->classes_pinned) (void)hipHostFree(ps->classes_pinned);
   delete ps;
@@ -1401,10 +1469,13 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
   hipError_t e = hipSuccess;
   if (get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) rc = 1;
   if (!rc) {
-    // use the adaptive order of the matching view if one exists (read-only here)
+    // use the adaptive order of the matching view if one exists (a record nothing has sorted yet is sorted first: production would, ahead
+    // of the view's next frame)
     for (auto &o : ps->orders)
-      if (o.h == h && o.w == w && o.part == p.part && o.nparts == p.nparts && o.max_depth == max_depth && o.valid &&
-          ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
+      if (o.h == h && o.w == w && o.part == p.part && o.nparts == p.nparts && o.max_depth == max_depth && o.rows_per_tile == 8 &&
+          std::memcmp(o.cam, &p.cam, sizeof o.cam) == 0 && ctx->adaptive_order && o.ntiles == p.nchunks && o.nshards == (p.interleave ? 1 : p.nshards)) {
+        if (sort_view(ctx, ps, &o, p, pl) || await_view(ctx, &o)) rc = 1;
+        if (!o.valid) continue;
         p.order = o.order;
         DeepPolicy dp;
         if (deep_policy(ctx, ps, &o, pl.grid_full * pl.waves, &dp, true)) rc = 1;
@@ -1413,7 +1484,7 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
         p.deep_cap_log2 = dp.cap_log2;
         if (dp.sparse && ctx->grid_div == 0) pl.grid = pl.grid_full;   // as enqueue_render launches this view
         // ... through its pixel list when enqueue_render would (same conditions)
-        if (o.px_valid && pl.waves == 16 && ctx->handover != 2 && ctx->adaptive_order == 1 && (p.nshards == 1 || p.interleave) &&
+        if (o.px_valid && pl.waves == 16 && ctx->adaptive_order == 1 && (p.nshards == 1 || p.interleave) &&
             o.px_elems >= static_cast<size_t>(p.rows_local) * p.w && o.rows_per_tile == 8 &&
             (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
                                        (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {

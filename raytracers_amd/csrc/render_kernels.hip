@@ -564,7 +564,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false>
 __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
-  static_assert(!ORD || TAIL == 0, "ORD: no tail variant");
+  static_assert(!ORD || TAIL != 1, "ORD: no COLD variant");   // (ORD + DONATE: a frame rendered through a pixel list BORROWED from a neighbouring view, round 6)
   static_assert(!CULL || !ALL_LDS, "CULL: instantiated for the general scene path only");
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
@@ -1737,7 +1737,8 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   // (ORD: pixel tickets; workgroups of 16 waves only)
   if (p.px_hdr != nullptr) {
     if (waves_per_wg != 16 || p.nframes != 1) return hipErrorInvalidValue;
-    // (p.solo clear: a list without a one-pixel class)
+    // (p.solo clear: a list without a one-pixel class; p.donate: with the DONATE tail -- a list borrowed from another view)
+    if (p.donate) return p.solo ? launch_pooled_16<false, true, 2, true>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 2, true>(p, all_lds, grid, stream);
     return p.solo ? launch_pooled_16<false, true, 0, true>(p, all_lds, grid, stream) : launch_pooled_16<false, false, 0, true>(p, all_lds, grid, stream);
   }
   // (COLD: small ordered single frames; DONATE: the first frame of a view; workgroups of 16 waves only -- other shapes render them with the ordinary kernels)
@@ -1781,7 +1782,13 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 0, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, true, 2, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 2, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true>);
   // ... and their CULL flavours
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, true, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 0, false, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 0, false, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 1, false, true>);

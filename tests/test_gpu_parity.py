@@ -633,6 +633,71 @@ def test_camera_path_one_frame_at_a_time(R, scene, h, w):
     c.close(); plain.close()
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(eager_sort=0), dict(borrow=0), dict(borrow=0, eager_sort=0), dict(pixel_order=0), dict(pixel_order=2, handover=2, donate_max=8),
+                                  dict(handover=0), dict(cull=1), dict(solo=0, thr_shade=8), dict(gpu_build=0, treelet=4), dict(xcd_queues=0, static_first=0), dict(adaptive_order=2)])
+def test_new_views_borrow_the_previous_views_order(R, opts):
+    """Round 6: a NEW view of a prepared scene (another camera, same image size / partition) renders its first frame through the order /
+    pixel list of the view rendered last (`borrow`), with the DONATE tail for the chains that list places wrongly (the ORD + DONATE
+    instantiation), while it records its own; and the sorts of a recorded view run on the context's SECOND stream behind the recording
+    frame (`eager_sort`) -- the next user of the order waits for their event.  A sliding camera, frame by frame, each frame against the
+    CPU checker through that camera: whole frames, a part packed and in place, a view re-rendered later (its own list by then), 13 views
+    (more than the 8 kept: the evicted views' buffers -- possibly still being sorted -- are taken over), and the knobs off."""
+    import torch
+    from raytracers_amd.dist import tile_rows
+    c = R.Context()
+    c.set_variant(3)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    for scene, h, w in (("irreg", 333, 250), ("rgbbox", 280, 400), ("floor:37:222", 90, 120)):
+        orc = _oracle(scene)
+        ps = R.prepare_scene(h, w, _scene(c, scene))
+        base = np.asarray(ps.camera(), dtype=np.float32).reshape(12)
+        cams = []
+        for f in range(13):
+            cam = base.copy()
+            cam[0] += np.float32(0.25 * f); cam[3] += np.float32(0.25 * f)
+            cams.append(cam)
+        want = [orc.render(h, w, cam=cam)[0] for cam in cams]
+        out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        seen = set()
+        for f in list(range(13)) + [2, 2, 12, 0, 0, 5]:
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(out.data_ptr(), h, w, ps, cam=cams[f])
+            c.sync()
+            ll = c.last_launch
+            assert int((out.cpu().numpy() != want[f]).sum()) == 0, (scene, f, ll)
+            if "waves=16" in ll and opts.get("adaptive_order", 1) == 1:
+                if f not in seen and seen and opts.get("borrow", 1):
+                    assert "(borrowed)" in ll and "recording=" in ll and "recording=0" not in ll, (scene, f, ll)
+                    if opts.get("handover", 1) and h * w > 4096 and "solo" not in opts and "treelet" not in opts:
+                        assert "DONATE" in ll, (scene, f, ll)
+                else:
+                    assert "(borrowed)" not in ll, (scene, f, ll)
+            seen.add(f)
+        # a part of three, packed and in place, along the same path (views of another partition: their own records and orders)
+        rows = R.part_rows(h, 1, 3)
+        part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
+        image = torch.full((h, w), -5, dtype=torch.int32, device="cuda")
+        mine = np.zeros(h, bool)
+        mine[tile_rows(h, 1, 3)] = True
+        for f in (0, 1, 2, 1):
+            part.fill_(-3)
+            torch.cuda.synchronize()
+            R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3, cam=cams[f])
+            c.sync()
+            assert int((part.cpu().numpy() != want[f][mine]).sum()) == 0, (scene, "part", f, c.last_launch)
+        for f in (3, 4, 3):
+            image.fill_(-5)
+            torch.cuda.synchronize()
+            R.render_inplace_into(image.data_ptr(), h, w, ps, part=1, nparts=3, cams=cams[f])
+            c.sync()
+            got = image.cpu().numpy()
+            assert int((got[mine] != want[f][mine]).sum()) == 0 and bool((got[~mine] == -5).all()), (scene, "in place", f, c.last_launch)
+        ps.free()
+    c.close()
+
+
 @pytest.mark.parametrize("seconds,seed,side,spheres", [(15, 77000, 160, 20000), (15, 88000, 520, 60000)])
 def test_random_parity_campaign(seconds, seed, side, spheres):
     """tools/fuzz_parity.py as a gate of the driver-run suite, half a minute of it: random scenes /

@@ -15,7 +15,7 @@ max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 160
 max_n = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
 ctx = R.Context()
 t_end = time.time() + budget
-cases = fails = culled_launches = 0
+cases = fails = culled_launches = borrowed_launches = 0
 while time.time() < t_end:
     seed = seed0 + cases
     rng = np.random.default_rng(seed)
@@ -78,7 +78,9 @@ while time.time() < t_end:
                  px_g1=int(rng.choice([0, 1, 25, 1000])), px_g8=int(rng.choice([0, 3, 45])), px_g16=int(rng.choice([0, 5, 65])),
                  px_g32=int(rng.choice([0, 7, 100])), px_g64=int(rng.choice([0, 9, 160, 5000])), px_ray_ns=int(rng.choice([0, 1, 300, 20000])),
                  # culling by the best hit so far (the CULL instantiations): off / where the library would / wherever the proof's guards hold
-                 cull=int(rng.choice([0, -1, 1, 1, 1])))
+                 cull=int(rng.choice([0, -1, 1, 1, 1])),
+                 # a new view borrows the previous view's order / pixel list; the sorts of a recorded view on the second stream or in line
+                 borrow=int(rng.choice([0, 1, 1, 1])), eager_sort=int(rng.choice([0, 1, 1])))
     for kv in os.environ.get("FUZZ_FORCE", "").split(","):     # e.g. FUZZ_FORCE=handover=2,donate_max=8: knobs pinned for an experiment
         if kv:
             knobs[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -101,6 +103,17 @@ while time.time() < t_end:
             ok &= int((px != ref).sum()) == 0 and int((px2 != ref).sum()) == 0
             if variant == 3:                            # third frame: the ticket counter after a frame with deep-tile pieces
                 ok &= int((R.render(h, w, ps, max_depth=md) != ref).sum()) == 0
+    # a second and a third camera on the same prepared scene: new views, rendered through the previous view's order / pixel list (borrow)
+    ctx.set_variant(3)
+    cam0 = np.asarray(ps.camera(), dtype=np.float32).reshape(12)
+    for step in (1, 2):
+        cam2 = cam0.copy()
+        cam2[0:3] += np.float32(0.01 * ext * step); cam2[3:6] += np.float32(0.01 * ext * step)
+        ref2, _ = orc.render(h, w, max_depth=md, threads=min(16, os.cpu_count() or 1), cam=cam2)
+        for rep in range(2):
+            got2 = R.render_image(ps, w, h, cam2, max_depth=md)
+            borrowed_launches += "(borrowed)" in ctx.last_launch
+            ok &= int((got2 != ref2).sum()) == 0
     # a batch of three frames in one launch (class-major tickets over the frames), after the view's order has settled
     ctx.set_variant(3)
     if h * w * 3 < (1 << 28):
@@ -139,5 +152,5 @@ while time.time() < t_end:
         fails += 1
         print(f"MISMATCH seed {seed}: n={n} kind={kind} ext={ext} {w}x{h} max_depth={md} knobs={knobs} nparts={nparts}", flush=True)
 ctx.set_option("gpu_build", 1)
-print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1}); {culled_launches} of the first / second frames ran a CULL instantiation", flush=True)
+print(f"fuzz: {cases} random cases, {fails} mismatches (seeds {seed0}..{seed0 + cases - 1}); {culled_launches} of the first / second frames ran a CULL instantiation, {borrowed_launches} frames of new views went through a borrowed order", flush=True)
 sys.exit(1 if fails else 0)
