@@ -648,13 +648,15 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     // Pixel tickets (the ORD instantiation): an ordered single frame of a view that has its pixel list draws from it -- every
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
-    if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 &&
+    if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 && !(borrowed && ctx->borrow == 2) &&
         (p.nshards == 1 || p.interleave) && use->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
         (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
                                    (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {
       p.px_list = use->px_list;
       p.px_hdr = reinterpret_cast<const int *>(use->px_list + use->px_elems);
-      p.px_hold = ctx->px_hold;
+      // (a BORROWED list: no class holds its wave -- the tickets' pixels are of equal length in the other view, not in this one, and a wave
+      // that waits for the slowest of 32 mispredicted chains idles: rgbbox 1000 x 1000 0.51 against 0.46 ms, profiles/r06/exp/e4)
+      p.px_hold = (borrowed && ctx->borrow != 3) ? 0 : ctx->px_hold;
       p.px_prio = ctx->px_prio;
       p.cold = 0;
       p.solo = (use->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
@@ -949,7 +951,7 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     drain_streams(ctx);            // (sorts in flight on either stream finish under the setting they were launched with)
     ctx->eager_sort = v != 0;
   } else if (k == "borrow") {
-    ctx->borrow = v != 0;
+    ctx->borrow = std::max(0, std::min(4, v));
   } else if (k == "cull") {
     ctx->cull = std::max(-1, std::min(1, v));
   } else if (k == "sync_policy") {

@@ -659,7 +659,7 @@ def test_new_views_borrow_the_previous_views_order(R, opts):
             cams.append(cam)
         want = [orc.render(h, w, cam=cam)[0] for cam in cams]
         out = torch.empty((h, w), dtype=torch.int32, device="cuda")
-        seen = set()
+        kept = []                                     # the library keeps the 8 most recently used views of a prepared scene
         for f in list(range(13)) + [2, 2, 12, 0, 0, 5]:
             out.fill_(-1)
             torch.cuda.synchronize()
@@ -668,13 +668,13 @@ def test_new_views_borrow_the_previous_views_order(R, opts):
             ll = c.last_launch
             assert int((out.cpu().numpy() != want[f]).sum()) == 0, (scene, f, ll)
             if "waves=16" in ll and opts.get("adaptive_order", 1) == 1:
-                if f not in seen and seen and opts.get("borrow", 1):
+                if f not in kept and kept and opts.get("borrow", 1):        # a view the prepared scene does not hold (any more): borrowed
                     assert "(borrowed)" in ll and "recording=" in ll and "recording=0" not in ll, (scene, f, ll)
                     if opts.get("handover", 1) and h * w > 4096 and "solo" not in opts and "treelet" not in opts:
                         assert "DONATE" in ll, (scene, f, ll)
                 else:
                     assert "(borrowed)" not in ll, (scene, f, ll)
-            seen.add(f)
+            kept = ([k for k in kept if k != f] + [f])[-8:]
         # a part of three, packed and in place, along the same path (views of another partition: their own records and orders)
         rows = R.part_rows(h, 1, 3)
         part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
@@ -1281,14 +1281,24 @@ def test_multi_device_real_devices(R):
         pytest.skip("one GPU")
     import bench
     import torch
+    import time
     mc = R.Context(devices=list(range(n)))
     assert mc.gather_mode == "direct-store"            # auto: every device can store into the first one's memory
+    report = []                                        # the first real multi-GPU run prints the two constants tools/scale_prediction.py assumes
     for gather in (3, 2, 1, 0):                        # direct stores over xGMI, RCCL send/recv, peer copies, auto
         mc.set_option("gather", gather)
         for scene, h, w in (("irreg", 4000, 4000), ("rgbbox", 1000, 1000)):
             ps = R.prepare_scene(h, w, mc.scene(scene))
             for rep in range(3):
                 assert O.checksum(R.render(h, w, ps)) == bench.FRAME_CHECKSUM[(scene, h, w)], (gather, rep)
+            # (timing, printed not asserted: render + exchange + sync per frame, as the reference's harness does)
+            img = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for rep in range(8):
+                R.render_into(img.data_ptr(), h, w, ps)
+                mc.sync()
+            one = (time.perf_counter() - t0) / 8 * 1e3
             # ... and a batch: every device its rows of all six frames in one launch (+ one gather, one assembly launch)
             buf = torch.full((6, h, w), -1, dtype=torch.int32, device="cuda:0")
             torch.cuda.synchronize()
@@ -1296,11 +1306,23 @@ def test_multi_device_real_devices(R):
             mc.sync()
             cks = bench.Checksummer(torch.device("cuda:0"))
             assert all(cks(buf[f]) == bench.FRAME_CHECKSUM[(scene, h, w)] for f in range(6)), gather
+            t0 = time.perf_counter()
+            R.render_batch_into(buf.data_ptr(), h, w, ps, 6, frame_stride=h * w)
+            mc.sync()
+            report.append(f"gather={gather} ({mc.gather_mode}, rccl_ranks {mc.rccl_ranks}) {scene} {w}x{h} on {n} devices: {one:.3f} ms per frame one at a time, "
+                          f"{(time.perf_counter() - t0) / 6 * 1e3:.3f} ms per frame in a batch of 6")
             ps.free()
         assert mc.gather_mode in {3: ("direct-store",), 2: ("rccl", "peer-copy"), 1: ("peer-copy",), 0: ("direct-store",)}[gather]
         if gather == 2 and mc.gather_mode == "rccl":   # distinct devices: one communicator rank per device carried the frames
             assert mc.rccl_ranks == n
     mc.close()
+    text = "\n".join(["multi-device timings (tools/scale_prediction.py models 25 us per ordering signal and half the link rate for 4-byte stores):"] + report)
+    print("\n" + text)
+    import warnings
+    warnings.warn(text)                                # (pytest -q hides a passing test's output; its warnings summary it prints)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "multi_device_timings.txt"), "a") as f:
+        f.write(text + "\n")
 
 
 def test_bench_line_on_two_real_gpus():
