@@ -103,7 +103,11 @@ build/tsan_nolock/ctx_threads: tools/ctx_threads.cpp $(CSRC)/api.cpp $(CSRC)/mul
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(TSAN) -o build/tsan_nolock/libray_mi355x.so $(OBJ)/render_kernels.o $(OBJ)/bvh_build.o build/tsan_nolock/api.o build/tsan_nolock/multi_gpu.o build/tsan/host_build.o -ldl
 	/opt/rocm/lib/llvm/bin/clang++ -O1 -std=c++17 $(TSAN) -Iinclude -pthread -o $@ tools/ctx_threads.cpp -Lbuild/tsan_nolock -lray_mi355x -Wl,-rpath,'$$ORIGIN'
 
-tools: build/ctx_threads build/rtbench build/issue_peak build/queue_check build/donate_check build/treelet_probe build/hip_touch build/cull_bound_check build/cull_pooled
+build/first_call_probe: tools/first_call_probe.c include/ray.h $(LIB)
+	@mkdir -p build
+	$(CC) -O2 -std=gnu99 -Wall -Iinclude -o $@ tools/first_call_probe.c -Lraytracers_amd -lray_mi355x -Wl,-rpath,'$$ORIGIN/../raytracers_amd'
+
+tools: build/first_call_probe build/ctx_threads build/rtbench build/issue_peak build/queue_check build/donate_check build/treelet_probe build/hip_touch build/cull_bound_check build/cull_pooled
 
 oracle:
 	$(MAKE) -s -C oracle

@@ -104,18 +104,19 @@ int upload(rt_context *ctx, T **dev, const void *host, size_t bytes) {
 int get_uv(rt_context *ctx, int64_t w, int64_t h, const float **u, const float **v) {
   for (const auto &t : ctx->uv)
     if (t.w == w && t.h == h) { *u = t.u; *v = t.v; return 0; }
-  std::vector<float> hu(static_cast<size_t>(w)), hv(static_cast<size_t>(h));
-  for (int64_t i = 0; i < w; ++i) hu[i] = rtk::pixel_u(static_cast<int>(i), static_cast<int>(w));
-  for (int64_t j = 0; j < h; ++j) hv[j] = rtk::pixel_v(static_cast<int>(j), static_cast<int>(h));
+  // (computed on the device, stream-ordered ahead of the frame, in a block of the context's arena: no hipMalloc, no blocking copy)
   rt_context::UvTable t{w, h, nullptr, nullptr};
-  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.u), hu.size() * 4));
-  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.v), hv.size() * 4));
-  RT_HIP(ctx, hipMemcpy(t.u, hu.data(), hu.size() * 4, hipMemcpyHostToDevice));
-  RT_HIP(ctx, hipMemcpy(t.v, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+  const size_t ub = (static_cast<size_t>(w) * 4 + 255) & ~size_t(255);
+  char *blk = nullptr;
+  size_t bytes = ub + static_cast<size_t>(h) * 4;
+  RT_HIP(ctx, pool_alloc(ctx, &blk, &bytes));
+  t.u = reinterpret_cast<float *>(blk);
+  t.v = reinterpret_cast<float *>(blk + ub);
+  t.bytes = bytes;
+  RT_HIP(ctx, rtk::launch_uv_tables(t.u, t.v, static_cast<int>(w), static_cast<int>(h), ctx->stream));
   if (ctx->uv.size() >= 16) {   // small LRU-less cap: drop the oldest
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->uv.front().u);
-    (void)hipFree(ctx->uv.front().v);
+    pool_free(ctx, reinterpret_cast<char *>(ctx->uv.front().u), ctx->uv.front().bytes);
     ctx->uv.erase(ctx->uv.begin());
   }
   ctx->uv.push_back(t);
@@ -133,12 +134,17 @@ int get_first_order(rt_context *ctx, int tiles_x, int tiles_y, const int **out) 
     if (t.tiles_x == tiles_x && t.tiles_y == tiles_y) { *out = t.order; return 0; }
   const int ntiles = tiles_x * tiles_y, nb = (tiles_x + 7) / 8;
   // (built on the device, stream-ordered ahead of the frame: no host copy, nothing waits)
-  rt_context::FirstOrder t{tiles_x, tiles_y, nullptr};
-  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(ntiles) + tiles_y + nb)));
+  rt_context::FirstOrder t{tiles_x, tiles_y, nullptr, 0};
+  {
+    char *blk = nullptr;
+    t.bytes = sizeof(int) * static_cast<size_t>(rtk::order_table_ints(ntiles) + tiles_y + nb);
+    RT_HIP(ctx, pool_alloc(ctx, &blk, &t.bytes));
+    t.order = reinterpret_cast<int *>(blk);
+  }
   RT_HIP(ctx, rtk::launch_first_order(t.order, t.order + rtk::order_table_ints(ntiles), tiles_x, tiles_y, ctx->stream));
   if (ctx->first_orders.size() >= 16) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->first_orders.front().order);
+    pool_free(ctx, reinterpret_cast<char *>(ctx->first_orders.front().order), ctx->first_orders.front().bytes);
     ctx->first_orders.erase(ctx->first_orders.begin());
   }
   ctx->first_orders.push_back(t);
@@ -274,9 +280,11 @@ struct DeepPolicy {
 };
 // The class table reaches the host without any render entry waiting for it: the frame that sorts a view's tiles enqueues a
 // copy of the table into a pinned slot (request_classes, below), and a later render of the view adopts it once that copy
-// has completed -- until then the view runs on the default setting (same pixels; a caller that syncs after every frame, as
-// the reference's harness does, has the policy from the view's second frame on, one that enqueues frames back to back a
-// few frames later).  `may_wait`: the diagnostic entry (rt_render_trace), which synchronises anyway.
+// has completed -- until then the view runs on the default setting (same pixels).  With eager_sort the sorts and the copy are launched
+// behind the recording frame, so a caller that syncs after every frame, as the reference's harness does, has the policy from the
+// view's second or third frame on; with eager_sort = 0 the copy is enqueued inside the view's second frame and the policy arrives
+// with its third; a caller that enqueues frames back to back gets it a few frames later.  Only the tile-ticket path reads it (views
+// outside the pixel list's gates); option sync_policy = 1 waits for it instead (measurements).  `may_wait`: the diagnostic entry (rt_render_trace), which synchronises anyway.
 int deep_policy(rt_context *ctx, const rt_prepared *ps, TileOrder *to, int waves_full, DeepPolicy *dp, bool may_wait = false) {
   *dp = DeepPolicy{ctx->deep_class < 0 ? 3 : ctx->deep_class, ctx->deep_split, ctx->deep_cap_log2, false};
   if (ctx->deep_class >= 0 || !to || !to->valid || to->nshards != 1) return 0;
@@ -312,8 +320,16 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to, hip
   rt_prepared *ps = const_cast<rt_prepared *>(ps_c);   // (the orders are `mutable` state of a prepared scene; so is their landing area)
   to->classes_pending = false;
   if (ctx->deep_class >= 0 || to->nshards != 1) return 0;   // no policy reads the table
-  if (!ps->classes_pinned)
-    RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * kClassSlotInts * kClassSlots, hipHostMallocDefault));
+  if (!ps->classes_pinned) {
+    for (int c = 0; c < kClassChunks && !ps->classes_pinned && ctx->class_slab; ++c)
+      if (!(ctx->class_chunks_used >> c & 1ull)) {
+        ctx->class_chunks_used |= 1ull << c;
+        ps->classes_chunk = c;
+        ps->classes_pinned = ctx->class_slab + static_cast<size_t>(c) * kClassSlotInts * kClassSlots;
+      }
+    if (!ps->classes_pinned)
+      RT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ps->classes_pinned), sizeof(int) * kClassSlotInts * kClassSlots, hipHostMallocDefault));
+  }
   if (to->classes_slot < 0) {
     unsigned used = 0;
     for (const auto &o : ps->orders)
@@ -338,21 +354,22 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to, hip
 int sort_view(rt_context *ctx, const rt_prepared *ps, TileOrder *v, const rtk::KParams &p, const Plan &pl) {
   if (!v->sort_pending) return 0;
   v->sort_pending = false;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream, st_px = ctx->stream;
   if (ctx->eager_sort) {
+    // (two sort streams: the tile order's three launches and the pixel list's four are independent and run side by side)
     if (!ctx->sort_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->sort_stream, hipStreamNonBlocking));
+    if (!ctx->sort_stream_px) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->sort_stream_px, hipStreamNonBlocking));
     if (!ctx->rec_event) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->rec_event, hipEventDisableTiming));
     RT_HIP(ctx, hipEventRecord(ctx->rec_event, ctx->stream));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream, ctx->rec_event, 0));
     st = ctx->sort_stream;
+    if (v->sort_px) {
+      RT_HIP(ctx, hipStreamWaitEvent(ctx->sort_stream_px, ctx->rec_event, 0));
+      st_px = ctx->sort_stream_px;
+    }
   }
-  if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
-  RT_HIP(ctx, rtk::launch_tile_order(v->cost, v->order, v->ntiles, p.tiles_x, v->nshards, ctx->order_scratch, st));
-  v->valid = true;
-  v->have_classes = false;
-  if (int rc = request_classes(ctx, ps, v, st)) return rc;
   if (v->sort_px) {
-    // ... and the view's pixel list from the per-pixel record
+    // the view's pixel list from the per-pixel record (first: a frame that borrows the list waits for this one)
     if (!ctx->px_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()));
     const rtk::PxGeom g{p.w, p.rows_local, p.rpt_log2, v->rec_out_skip, p.tiles_x, p.tiles_y};
     rtk::PxPolicy pol{};
@@ -368,9 +385,19 @@ int sort_view(rt_context *ctx, const rt_prepared *ps, TileOrder *v, const rtk::K
     pol.solo_cap = (ctx->solo && ps->tl_depth == rtk::kTreeletDepth && p.nchunks <= 32768) ? pl.grid_full * pl.waves / std::max(1, ctx->px_solo_div) : 0;
     v->px_solo = pol.solo_cap > 0;
     pol.zip = ctx->px_zip;
-    RT_HIP(ctx, rtk::launch_px_order(v->cost_px, g, pol, v->px_list, reinterpret_cast<int *>(v->px_list + v->px_elems), ctx->px_scratch, st));
+    RT_HIP(ctx, rtk::launch_px_order(v->cost_px, g, pol, v->px_list, reinterpret_cast<int *>(v->px_list + v->px_elems), ctx->px_scratch, st_px));
     v->px_valid = true;
+    if (st_px != ctx->stream) {
+      if (!v->sort_event_px) RT_HIP(ctx, hipEventCreateWithFlags(&v->sort_event_px, hipEventDisableTiming));
+      RT_HIP(ctx, hipEventRecord(v->sort_event_px, st_px));
+      v->sort_inflight_px = true;
+    }
   }
+  if (!ctx->order_scratch) RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts));
+  RT_HIP(ctx, rtk::launch_tile_order(v->cost, v->order, v->ntiles, p.tiles_x, v->nshards, ctx->order_scratch, st));
+  v->valid = true;
+  v->have_classes = false;
+  if (int rc = request_classes(ctx, ps, v, st)) return rc;
   if (st != ctx->stream) {
     if (!v->sort_event) RT_HIP(ctx, hipEventCreateWithFlags(&v->sort_event, hipEventDisableTiming));
     RT_HIP(ctx, hipEventRecord(v->sort_event, st));
@@ -380,15 +407,33 @@ int sort_view(rt_context *ctx, const rt_prepared *ps, TileOrder *v, const rtk::K
 }
 // the main stream waits for a view's sorts (once: everything behind the wait is ordered after them)
 int await_view(rt_context *ctx, TileOrder *v) {
-  if (!v->sort_inflight) return 0;
-  RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->sort_event, 0));
-  v->sort_inflight = false;
+  if (v->sort_inflight) {
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->sort_event, 0));
+    v->sort_inflight = false;
+  }
+  if (v->sort_inflight_px) {
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->sort_event_px, 0));
+    v->sort_inflight_px = false;
+  }
   return 0;
+}
+// have the view's sorts finished on the device?  (never blocks; clears the in-flight flags when they have: nothing needs to wait any more)
+bool sorts_complete(TileOrder *v) {
+  if (v->sort_inflight) {
+    if (hipEventQuery(v->sort_event) != hipSuccess) { (void)hipGetLastError(); return false; }
+    v->sort_inflight = false;
+  }
+  if (v->sort_inflight_px) {
+    if (hipEventQuery(v->sort_event_px) != hipSuccess) { (void)hipGetLastError(); return false; }
+    v->sort_inflight_px = false;
+  }
+  return true;
 }
 // both streams drained (before buffers the sorts may touch are freed)
 void drain_streams(rt_context *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->sort_stream) (void)hipStreamSynchronize(ctx->sort_stream);
+  if (ctx->sort_stream_px) (void)hipStreamSynchronize(ctx->sort_stream_px);
 }
 
 // May this launch cull (lane_core.h: cull_limit)?  The scene's guards (rt_prepared::cull), the launch shape the CULL instantiations
@@ -527,6 +572,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
+    // May a view of this shape ever render through a pixel list (the ORD launch condition's static part)?  Only then does it get the
+    // per-pixel buffers (5 bytes per pixel) and does its first frame store the per-pixel record.
+    const bool px_static_ok = ctx->pixel_order == 2 ||
+                              (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && pl.waves == 16 && ctx->adaptive_order == 1 && p.nchunks <= ctx->px_max_tiles &&
+                               (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph)));
     TileOrder *to = nullptr;      // the view this frame belongs to (its record, its order, its pixel list)
     TileOrder *use = nullptr;     // the view whose order / pixel list this frame is rendered through: `to`, or the view it borrows from
     bool borrowed = false;
@@ -543,9 +593,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         // hipFree / hipMalloc per new view).
         TileOrder o{};
         // (pixel tickets: the per-pixel record and the pixel list of the view, if this context may use them)
-        const bool px_ok = ctx->pixel_order != 0 && w < 65536 && p.rows_local < 65536 && (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
+        const bool px_ok = px_static_ok && w < 65536 && p.rows_local < 65536;
         const size_t px_bytes = px_ok ? static_cast<size_t>(h) * static_cast<size_t>(w) : 0;
         const size_t px_elems = px_ok ? static_cast<size_t>(p.rows_local) * static_cast<size_t>(p.w) : 0;
+        auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+        const size_t off_order = up(sizeof(int) * static_cast<size_t>(p.nchunks)), off_cost_px = off_order + up(sizeof(int) * static_cast<size_t>(rtk::order_table_ints(p.nchunks))),
+                     off_px_list = off_cost_px + up(px_bytes), need_bytes = off_px_list + up(sizeof(unsigned) * (px_elems + (px_ok ? rtk::kPxHdrInts : 0)));
         if (ps->orders.size() >= 8) {
           size_t lru = 0;
           for (size_t i = 1; i < ps->orders.size(); ++i)
@@ -554,18 +607,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           o.classes_event = v.classes_event;   // (a copy still in flight lands in the slot before any later one: same stream)
           o.classes_slot = v.classes_slot;
           o.sort_event = v.sort_event;
+          o.sort_event_px = v.sort_event_px;
           if (int rc = await_view(ctx, &v)) return rc;   // (sorts of the evicted view still running on the sort stream touch these buffers: the main stream goes behind them)
-          if (v.ntiles == p.nchunks && v.cost_px_bytes >= px_bytes && v.px_elems >= px_elems && (px_ok || !v.px_list)) {
-            o.cost = v.cost;
-            o.order = v.order;
-            o.cost_px = v.cost_px; o.cost_px_bytes = v.cost_px_bytes;
-            o.px_list = v.px_list; o.px_elems = v.px_elems;
+          if (v.block_bytes >= need_bytes) {       // the evicted view's block as it is
+            o.block = v.block;
+            o.block_bytes = v.block_bytes;
           } else {
             drain_streams(ctx);
-            (void)hipFree(v.cost);
-            (void)hipFree(v.order);
-            (void)hipFree(v.cost_px);
-            (void)hipFree(v.px_list);
+            pool_free(ctx, v.block, v.block_bytes);
           }
           ps->orders.erase(ps->orders.begin() + static_cast<std::ptrdiff_t>(lru));
         }
@@ -573,13 +622,17 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         std::memcpy(o.cam, &p.cam, sizeof o.cam);
         o.ntiles = p.nchunks;
         o.nshards = order_shards;
-        if (!o.order) {
-          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost), sizeof(int) * static_cast<size_t>(o.ntiles)));
-          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.order), sizeof(int) * static_cast<size_t>(rtk::order_table_ints(o.ntiles))));
+        // one block of the context's arena / block pool behind the view's four arrays (a hipMalloc each inside a view's first render call
+        // cost the reference's harness ~0.3 ms of its first frame)
+        if (!o.block) {
+          o.block_bytes = need_bytes;
+          RT_HIP(ctx, pool_alloc(ctx, &o.block, &o.block_bytes));
         }
-        if (px_ok && !o.px_list) {
-          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.cost_px), px_bytes));
-          RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.px_list), sizeof(unsigned) * (px_elems + rtk::kPxHdrInts)));
+        o.cost = reinterpret_cast<int *>(o.block);
+        o.order = reinterpret_cast<int *>(o.block + off_order);
+        if (px_ok) {
+          o.cost_px = reinterpret_cast<unsigned char *>(o.block + off_cost_px);
+          o.px_list = reinterpret_cast<unsigned *>(o.block + off_px_list);
           o.cost_px_bytes = px_bytes;
           o.px_elems = px_elems;
         }
@@ -596,10 +649,27 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // frames -- which were unordered (tiles in bit-reversed order, DONATE tail).  Neighbouring views agree on WHERE the long chains
       // are (they cluster at the walls' edges / at grazing angles, profiles/r04/README.md) even though single pixels do not; the
       // chains the borrowed list places wrongly are what the DONATE tail catches.  Only the order of independent pixels changes.
+      // WHICH view: the most recently rendered one whose sorts have COMPLETED (an event query: nothing waits) -- a caller that synchronises
+      // after every frame finds the view before the previous one there, the previous view's sorts still running.  If none has: the second
+      // most recent one (a caller that enqueues its frames back to back: the most recent view's sorts cannot start before its frame ends,
+      // and this frame would wait for both -- the camera path of the bench, frame by frame without a sync: 0.52 ms per frame that way,
+      // 0.49 unordered), else the most recent one (the second view of a path: waiting ~0.05 ms for its sorts beats rendering unordered).
       if (!use && ctx->borrow && nframes == 1 && ctx->adaptive_order == 1) {
-        TileOrder *from = nullptr;
-        for (auto &o : ps->orders)
-          if (&o != to && same_shape(o) && (o.valid || o.sort_pending) && (!from || o.stamp > from->stamp)) from = &o;
+        TileOrder *done = nullptr, *fl1 = nullptr, *fl2 = nullptr;
+        for (auto &o : ps->orders) {
+          if (&o == to || !same_shape(o) || !(o.valid || o.sort_pending)) continue;
+          if (!o.sort_pending && sorts_complete(&o)) {
+            if (!done || o.stamp > done->stamp) done = &o;
+          } else if (!fl1 || o.stamp > fl1->stamp) {
+            fl2 = fl1;
+            fl1 = &o;
+          } else if (!fl2 || o.stamp > fl2->stamp) {
+            fl2 = &o;
+          }
+        }
+        // (the most recent of {a view whose sorts are through, the second most recent view still being sorted}; the most recent view still
+        // being sorted only if there is nothing else: a caller far ahead of the device would otherwise borrow from a view many frames back)
+        TileOrder *from = (done && fl2) ? (done->stamp > fl2->stamp ? done : fl2) : (done ? done : (fl2 ? fl2 : fl1));
         if (from) {
           if (int rc = sort_view(ctx, ps, from, p, pl)) return rc;
           use = from;
@@ -612,9 +682,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // once (after the view's first frame) and kept; adaptive_order == 2 re-records and
       // recomputes every frame (testing aid).
       // (a view whose tiles were first recorded by a batch has no per-pixel record yet: its first single frame records again)
-      const bool px_can = ctx->pixel_order != 0 && nframes == 1 && to->px_list != nullptr && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-                          to->cost_px_bytes >= static_cast<size_t>(h) * w && w < 65536 && p.rows_local < 65536 && (p.nshards == 1 || p.interleave) &&
-                          (ctx->pixel_order == 2 || p.nchunks <= ctx->px_max_tiles);
+      const bool px_can = px_static_ok && nframes == 1 && to->px_list != nullptr && to->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
+                          to->cost_px_bytes >= static_cast<size_t>(h) * w && w < 65536 && p.rows_local < 65536 && (p.nshards == 1 || p.interleave);
       const bool rerecord = !to->valid || ctx->adaptive_order == 2 || (px_can && !to->px_valid);
       p.cost = rerecord ? to->cost : nullptr;
       p.cost_px = rerecord && px_can ? to->cost_px : nullptr;
@@ -648,15 +717,19 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     // Pixel tickets (the ORD instantiation): an ordered single frame of a view that has its pixel list draws from it -- every
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
-    if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 && !(borrowed && ctx->borrow == 2) &&
-        (p.nshards == 1 || p.interleave) && use->px_elems >= static_cast<size_t>(p.rows_local) * p.w &&
-        (ctx->pixel_order == 2 || (ctx->pixel_order == 1 && ctx->deep_class < 0 && max_depth > 4 && p.nchunks <= ctx->px_max_tiles &&
-                                   (p.nchunks >= 1024 || (pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph))))) {
+    // (a BORROWED order, `borrow` = 1: through the other view's pixel list, holds and all, when the scene is read from L2; through its TILE order
+    // when the scene lives in LDS.  Camera path view by view, mean of the views behind the first, none / tiles / list / list without holds,
+    // profiles/r06/exp/e4_borrow_modes_*.txt: irreg 500 x 500 0.315 / 0.308 / 0.267 / 0.271 ms, 1000 x 1000 0.506 / 0.453 / 0.376 / 0.402,
+    // 1400 x 1400 0.620 / 0.556 / 0.498 / 0.516; rgbbox 0.335 / 0.313 / 0.343 / 0.347, 0.561 / 0.508 / 0.551 / 0.553, 0.785 / 0.734 / 0.791 / 0.803:
+    // irreg's long chains sit at the same pixels in neighbouring views -- grazing rays over the floor --, rgbbox's are chaotic pixel by pixel and
+    // stable only tile by tile.)
+    const bool whole_in_lds = pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph;
+    const bool borrow_tiles_only = borrowed && (ctx->borrow == 2 || (ctx->borrow == 1 && whole_in_lds));
+    if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 && !borrow_tiles_only &&
+        (p.nshards == 1 || p.interleave) && use->px_elems >= static_cast<size_t>(p.rows_local) * p.w && px_static_ok) {
       p.px_list = use->px_list;
       p.px_hdr = reinterpret_cast<const int *>(use->px_list + use->px_elems);
-      // (a BORROWED list: no class holds its wave -- the tickets' pixels are of equal length in the other view, not in this one, and a wave
-      // that waits for the slowest of 32 mispredicted chains idles: rgbbox 1000 x 1000 0.51 against 0.46 ms, profiles/r06/exp/e4)
-      p.px_hold = (borrowed && ctx->borrow != 3) ? 0 : ctx->px_hold;
+      p.px_hold = (borrowed && ctx->borrow == 4) ? 0 : ctx->px_hold;   // (borrow = 4, testing: a borrowed list without its holds)
       p.px_prio = ctx->px_prio;
       p.cold = 0;
       p.solo = (use->px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
@@ -779,6 +852,14 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), rtk::gpu_build_pinned_bytes(), hipHostMallocDefault) != hipSuccess)
     return bail(7);
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), kStageBytes, hipHostMallocDefault) != hipSuccess) return bail(7);
+  // The sort streams, their event and the sorts' scratch: created here, not at a view's first recording frame -- a HIP stream is a
+  // hardware queue (milliseconds to create), and the reference's harness times its first render call with the rest (main.c:107-124).
+  if (hipStreamCreateWithFlags(&ctx->sort_stream, hipStreamNonBlocking) != hipSuccess) return bail(6);
+  if (hipStreamCreateWithFlags(&ctx->sort_stream_px, hipStreamNonBlocking) != hipSuccess) return bail(6);
+  if (hipEventCreateWithFlags(&ctx->rec_event, hipEventDisableTiming) != hipSuccess) return bail(6);
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->order_scratch), sizeof(int) * rtk::kOrderScratchInts) != hipSuccess) return bail(7);
+  if (hipMalloc(reinterpret_cast<void **>(&ctx->px_scratch), sizeof(int) * rtk::px_scratch_ints()) != hipSuccess) return bail(7);
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->class_slab), sizeof(int) * kClassSlotInts * kClassSlots * kClassChunks, hipHostMallocDefault) != hipSuccess) return bail(7);
   rtk::warm_render_kernels();
   rtk::warm_build_kernels();
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
@@ -796,12 +877,11 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   (void)hipSetDevice(ctx->device);
   drain_streams(ctx);
   if (ctx->sort_stream) (void)hipStreamDestroy(ctx->sort_stream);
+  if (ctx->sort_stream_px) (void)hipStreamDestroy(ctx->sort_stream_px);
   if (ctx->rec_event) (void)hipEventDestroy(ctx->rec_event);
-  for (auto &t : ctx->uv) {
-    (void)hipFree(t.u);
-    (void)hipFree(t.v);
-  }
-  for (auto &t : ctx->first_orders) (void)hipFree(t.order);
+  for (auto &t : ctx->uv) pool_free(ctx, reinterpret_cast<char *>(t.u), t.bytes);
+  for (auto &t : ctx->first_orders) pool_free(ctx, reinterpret_cast<char *>(t.order), t.bytes);
+  if (ctx->class_slab) (void)hipHostFree(ctx->class_slab);
   if (ctx->cams_dev) (void)hipFree(ctx->cams_dev);
   if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
@@ -910,6 +990,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->trace_part = v;
   } else if (k == "trace_nparts") {
     ctx->trace_nparts = v;
+  } else if (k == "trace_solo") {
+    ctx->trace_solo = v != 0;
   } else if (k == "ray_planes") {
     if (v != 0 && v != 2 && v != 3) return fail(ctx, "ray_planes must be 0 (auto), 2 or 3");
     ctx->ray_planes = v;
@@ -1159,14 +1241,13 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   }
   pool_free(ctx, ps->block, ps->block_bytes);
   for (auto &o : ps->orders) {
-    (void)hipFree(o.cost);
-    (void)hipFree(o.order);
-    (void)hipFree(o.cost_px);
-    (void)hipFree(o.px_list);
+    pool_free(ctx, o.block, o.block_bytes);
     if (o.classes_event) (void)hipEventDestroy(o.classes_event);
     if (o.sort_event) (void)hipEventDestroy(o.sort_event);
+    if (o.sort_event_px) (void)hipEventDestroy(o.sort_event_px);
   }
-  if (ps->classes_pinned) (void)hipHostFree(ps->classes_pinned);
+  if (ps->classes_pinned && ps->classes_chunk < 0) (void)hipHostFree(ps->classes_pinned);
+  if (ps->classes_chunk >= 0 && ctx) ctx->class_chunks_used &= ~(1ull << ps->classes_chunk);
   delete ps;
   return 0;
 }
@@ -1494,9 +1575,10 @@ extern "C" int rt_render_trace(rt_context *ctx, const rt_prepared *ps, int64_t h
           p.px_hdr = reinterpret_cast<const int *>(o.px_list + o.px_elems);
           p.px_hold = ctx->px_hold;
           p.px_prio = ctx->px_prio;
-          // (the instrumented launch walks a list's one-pixel tickets in the pooled loop, as tickets of one held pixel: solo_trace keeps
-          // no counters, and the trace's item counts are meant to be the frame's complete work)
-          p.solo = 0;
+          // (the instrumented launch walks a list's one-pixel tickets in the pooled loop, as tickets of one held pixel -- the trace's item
+          // counts are then the frame's complete work --, unless trace_solo asks for the production path: solo_trace with its own cycle
+          // counters, words 13 .. 15 of a wave's record)
+          p.solo = (ctx->trace_solo && o.px_solo && ctx->solo && ps->tl_depth == rtk::kTreeletDepth) ? 1 : 0;
           if (ctx->grid_div == 0 && pl.grid != pl.grid_full) {
             const int ns = (xq && pl.grid_full % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
             const int il = ns > 1 && xq == 2;

@@ -403,17 +403,51 @@ __global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int 
   if ((threadIdx.x & 63) == 0) atomicMax(maxdepth, d);
 }
 
-// ---- treelet-major numbering (treelet.h, cut of depth 2) ---------------------------------------
-// From the numbering by depth (order[t] = canonical node, depth_sorted[t] its depth, trav_of its inverse): a node of even
-// depth and its inner children become neighbours -- {node, left inner child, right inner child} -- and these treelets keep
-// the order of their roots, so the nodes nearest the root still form a prefix.  size[t] = nodes of the treelet rooted at the
-// t-th node (0 for a node of odd depth); its exclusive scan is where each treelet starts.
+// ---- treelet-major numbering (treelet.h, cut of kTreeletDepth levels) ---------------------------
+// From the numbering by depth (order[t] = canonical node, depth_sorted[t] its depth, trav_of its inverse): a node whose depth is a
+// multiple of D and its descendants of relative depth < D become neighbours, in the order of their heap indices inside the treelet
+// (root 0, children of h at 2h + 1 and 2h + 2), compacted; the treelets keep the order of their roots, so the nodes nearest the root
+// still form a prefix.  size[t] = nodes of the treelet rooted at the t-th node (0 for a node that is no root); its exclusive scan is
+// where each treelet starts.  A treelet has at most 2^D - 1 <= 15 nodes: every node recomputes what it needs of its own treelet
+// from the child links (no per-treelet arrays).
+// occupancy of the treelet rooted at canonical node r: bit h = an inner node sits at heap index h
+__device__ __forceinline__ uint32_t treelet_occ(int r, const int *left, const int *right) {
+  constexpr int D = kTreeletDepth, kInner = (1 << (D - 1)) - 1;   // heap indices whose children lie inside the treelet
+  uint32_t occ = 1u;
+  int node[kInner > 0 ? kInner : 1];
+  node[0] = r;
+#pragma unroll
+  for (int h = 0; h < kInner; ++h) {
+    if (!((occ >> h) & 1u)) continue;
+    const int c = node[h], l = left[c], rr = right[c];
+    if (l >= 0) {
+      occ |= 1u << (2 * h + 1);
+      if (2 * h + 1 < kInner) node[2 * h + 1] = l;
+    }
+    if (rr >= 0) {
+      occ |= 1u << (2 * h + 2);
+      if (2 * h + 2 < kInner) node[2 * h + 2] = rr;
+    }
+  }
+  return occ;
+}
+// canonical node c at relative depth `rel` of its treelet: the treelet's root and c's heap index (the step nearest the root is the most
+// significant path bit -- host_build.cpp: make_trav_layout)
+__device__ __forceinline__ int treelet_root(int c, int rel, const int *parent, const int *right, int *heap) {
+  int a = c, path = 0;
+  for (int s = 0; s < rel; ++s) {
+    const int p = parent[a];
+    path |= (right[p] == a ? 1 : 0) << s;
+    a = p;
+  }
+  *heap = (1 << rel) - 1 + path;
+  return a;
+}
 __global__ __launch_bounds__(kBT) void treelet_size_kernel(const unsigned *depth_sorted, const int *order, const int *left,
                                                            const int *right, int ni, unsigned *size) {
   const int t = blockIdx.x * kBT + threadIdx.x;
   if (t >= ni) return;
-  const int c = order[t];
-  size[t] = (depth_sorted[t] & 1u) ? 0u : 1u + (left[c] >= 0 ? 1u : 0u) + (right[c] >= 0 ? 1u : 0u);
+  size[t] = (depth_sorted[t] % (unsigned)kTreeletDepth) ? 0u : (unsigned)tl_popc(treelet_occ(order[t], left, right));
 }
 constexpr int kScanE = 4;   // elements per thread of the multi-block scan
 __global__ __launch_bounds__(kBT) void scan_sums_kernel(const unsigned *v, int n, unsigned *sums) {
@@ -441,15 +475,20 @@ __global__ __launch_bounds__(kBT) void scan_apply_kernel(unsigned *v, int n, con
     run += x[e];
   }
 }
-// a node's new index (+ its place in its treelet, packed: treelet.h) from the treelet starts
+// a node's new index (+ its heap index in its treelet, packed: treelet.h) from the treelet starts
 __device__ __forceinline__ unsigned treelet_place(int c, const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
                                                  const int *parent, const int *left, const int *right) {
-  const int t = trav_by_depth[c];
-  if (!(depth_sorted[t] & 1u)) return tl_pack_place(start[t], false, false, 0);
-  const int p = parent[c];
-  const bool is_right = right[p] == c;
-  const int pos = 1 + (is_right && left[p] >= 0 ? 1 : 0);
-  return tl_pack_place(start[trav_by_depth[p]] + (unsigned)pos, true, is_right, pos);
+  const int rel = (int)(depth_sorted[trav_by_depth[c]] % (unsigned)kTreeletDepth);
+  int heap;
+  const int r = treelet_root(c, rel, parent, right, &heap);
+  return tl_pack_place(start[trav_by_depth[r]] + (unsigned)tl_pos(treelet_occ(r, left, right), heap), heap);
+}
+// the two mask dwords of canonical node c, whose packed place is `place` (treelet.h: tl_masks)
+__device__ __forceinline__ TlMasks treelet_masks(int c, unsigned place, const int *parent, const int *left, const int *right) {
+  const int heap = tl_place_heap(place);
+  int h2;
+  const int r = treelet_root(c, tl_heap_level(heap), parent, right, &h2);
+  return tl_masks(treelet_occ(r, left, right), heap, kTreeletDepth);
 }
 __global__ __launch_bounds__(kBT) void treelet_number_kernel(const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
                                                              const int *parent, const int *left, const int *right, int ni,
@@ -467,7 +506,7 @@ __global__ __launch_bounds__(kBT) void invert_kernel(const int *order, int ni, i
 }
 
 // ---- traversal copy ---------------------------------------------------------------------------
-__device__ __forceinline__ void trav_node(int t, const int *order, const int *trav_of, const int *left, const int *right,
+__device__ __forceinline__ void trav_node(int t, const int *order, const int *trav_of, const int *parent, const int *left, const int *right,
                                           const float *bmin, const float *bmax, float4 *nodes32, float4 *nodes64) {
   const int c = order[t];
   const int kid[2] = {left[c], right[c]};
@@ -487,7 +526,7 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
   }
   q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted: a pooled work item is (reference << 8) | (slot * 4)
   q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
-  const TlMasks tm = tl_masks_depth2((unsigned)trav_of[c]);   // the node's place in its treelet (treelet.h)
+  const TlMasks tm = treelet_masks(c, (unsigned)trav_of[c], parent, left, right);   // the node's place in its treelet (treelet.h)
   q[2].w = __int_as_float((int)tm.l);
   q[3].w = __int_as_float((int)tm.r);
   nodes64[4 * (size_t)t + 0] = q[0];
@@ -498,11 +537,11 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
   nodes32[2 * (size_t)t + 0] = make_float4(mn[0], mn[1], mn[2], __int_as_float(ref[0]));
   nodes32[2 * (size_t)t + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(ref[1]));
 }
-__global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const int *trav_of, const int *left,
+__global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const int *trav_of, const int *parent, const int *left,
                                                          const int *right, const float *bmin, const float *bmax, int ni,
                                                          float4 *nodes32, float4 *nodes64) {
   const int t = blockIdx.x * kBT + threadIdx.x;
-  if (t < ni) trav_node(t, order, trav_of, left, right, bmin, bmax, nodes32, nodes64);
+  if (t < ni) trav_node(t, order, trav_of, parent, left, right, bmin, bmax, nodes32, nodes64);
 }
 
 __global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int n, float4 *sph, float4 *col) {
@@ -716,7 +755,7 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
   int *order = a.order, *trav_of = a.trav_of;   // global: LDS is about to hold the work lists
   for (int t = tid; t < ni; t += kSmallNT) trav_of[(int)lv[t]] = t;
   // ... then treelet by treelet (treelet.h; the multi-kernel path's treelet_size / scan / treelet_number in one block):
-  // lk[t] becomes the start of the treelet rooted at the t-th node of the order by depth, the depth's parity kept in bit 0
+  // lk[t] becomes the start of the treelet rooted at the t-th node of the order by depth, the depth's residue mod D kept in bits 0..2
   {
     const int E = ((ni + kSmallNT - 1) / kSmallNT) | 1;
     const int base = tid * E;
@@ -726,7 +765,9 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
       sz[e] = 0;
       if (e < E && base + e < ni) {
         const int c = (int)lv[base + e];
-        sz[e] = (lk[base + e] & 1u) ? 0u : 1u + (a.o.left[c] >= 0 ? 1u : 0u) + (a.o.right[c] >= 0 ? 1u : 0u);
+        const unsigned rel = lk[base + e] % (unsigned)kTreeletDepth;
+        sz[e] = rel ? 0u : (unsigned)tl_popc(treelet_occ(c, a.o.left, a.o.right));
+        lk[base + e] = rel;          // (only this thread touches its own entries until the sync below)
         sum += sz[e];
       }
     }
@@ -735,7 +776,7 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
 #pragma unroll
     for (int e = 0; e < kSmallE; ++e)
       if (e < E && base + e < ni) {
-        lk[base + e] = (run << 1) | (lk[base + e] & 1u);
+        lk[base + e] = (run << 3) | lk[base + e];
         run += sz[e];
       }
     __syncthreads();
@@ -743,21 +784,16 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
 #pragma unroll
     for (int e = 0; e < kSmallE; ++e)
       if (e < E && base + e < ni) {   // canonical node base + e
-        const int c = base + e, t = trav_of[c];
-        if (!(lk[t] & 1u)) {
-          pl[e] = tl_pack_place(lk[t] >> 1, false, false, 0);
-        } else {
-          const int p = a.o.parent[c];
-          const bool is_right = a.o.right[p] == c;
-          const int pos = 1 + (is_right && a.o.left[p] >= 0 ? 1 : 0);
-          pl[e] = tl_pack_place((lk[trav_of[p]] >> 1) + (unsigned)pos, true, is_right, pos);
-        }
+        const int c = base + e;
+        int heap;
+        const int r = treelet_root(c, (int)(lk[trav_of[c]] & 7u), a.o.parent, a.o.right, &heap);
+        pl[e] = tl_pack_place((lk[trav_of[r]] >> 3) + (unsigned)tl_pos(treelet_occ(r, a.o.left, a.o.right), heap), heap);
       }
     __syncthreads();   // every by-depth index has been read
 #pragma unroll
     for (int e = 0; e < kSmallE; ++e)
       if (e < E && base + e < ni) {
-        trav_of[base + e] = (int)pl[e];                 // index + place, packed
+        trav_of[base + e] = (int)pl[e];                 // index + heap index, packed
         order[pl[e] & kTlIndexMask] = base + e;
       }
   }
@@ -871,7 +907,7 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
     }
     q[0].w = __int_as_float((int)((unsigned)ref[0] << 8));   // pre-shifted (see trav_node)
     q[1].w = __int_as_float((int)((unsigned)ref[1] << 8));
-    const TlMasks tm = tl_masks_depth2((unsigned)trav_of[c]);
+    const TlMasks tm = treelet_masks(c, (unsigned)trav_of[c], a.o.parent, a.o.left, a.o.right);
     q[2].w = __int_as_float((int)tm.l);
     q[3].w = __int_as_float((int)tm.r);
     a.o.nodes64[4 * (size_t)t + 0] = q[0];
@@ -1067,7 +1103,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
     hipLaunchKernelGGL(scan_apply_kernel, dim3(sb), dim3(kBT), 0, st, start, ni, counts);
     hipLaunchKernelGGL(treelet_number_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], start, trav_of, o.parent, o.left, o.right, ni,
                        place, order2);
-    hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, order2, place, o.left, o.right, o.bmin, o.bmax, ni, o.nodes32,
+    hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, order2, place, o.parent, o.left, o.right, o.bmin, o.bmax, ni, o.nodes32,
                        o.nodes64);
   }
   hipLaunchKernelGGL(trav_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, o.L7, n, o.sph, o.col);
@@ -1125,6 +1161,20 @@ hipError_t launch_first_order(int *order, int *rank, int tiles_x, int tiles_y, h
   if (hipError_t e = hipMemsetAsync(order + ntiles, 0, sizeof(int) * (size_t)(order_table_ints(ntiles) - ntiles), stream); e != hipSuccess) return e;
   hipLaunchKernelGGL(first_order_rank_kernel, dim3((tiles_y + nb + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank);
   hipLaunchKernelGGL(first_order_fill_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank, order);
+  return hipGetLastError();
+}
+
+// The primary rays' u = i / w and v = (h - row) / h (trace_ray, ray.fut:150-154; lane_core.h: pixel_u / pixel_v) per column / row, computed
+// on the device: the same correctly rounded binary32 divisions the host would make -- no host table, no blocking copy inside a view's
+// first render call.
+__global__ void uv_tables_kernel(float *u, float *v, int w, int h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < w) u[i] = pixel_u(i, w);
+  if (i < h) v[i] = pixel_v(i, h);
+}
+hipError_t launch_uv_tables(float *u, float *v, int w, int h, hipStream_t stream) {
+  const int n = w > h ? w : h;
+  hipLaunchKernelGGL(uv_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, u, v, w, h);
   return hipGetLastError();
 }
 

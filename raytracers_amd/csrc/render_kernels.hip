@@ -402,7 +402,9 @@ __device__ __forceinline__ unsigned lds_load4(unsigned a) { return *reinterpret_
 // are walked: the limit never bites and costs its instructions on the frame's critical path.  Measured with it on, round 6:
 // irreg 1000 x 1000 one frame at a time 0.249 -> 0.256 ms, 500 x 500 0.218 -> 0.226; profiles/r06/exp/e1_cull_ab.txt.)
 constexpr bool kSoloCull = false;
-template <bool CULL>
+// TRACE (the instrumented launch, rt_render_trace with option trace_solo): shader cycles inside treelet operations, sphere-test operations and the
+// rest of a bounce (ray_derive, root box, winner's loads, shade), with their counts, added to words 13 .. 15 of the wave's trace record.
+template <bool CULL, bool TRACE = false>
 __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned smem_lds, unsigned wbase_lds, float ox, float oy, float oz,
                                                      float dx, float dy, float dz, float lr, float lg, float lb, int pix, int depth,
                                                      int ptile) {
@@ -429,8 +431,25 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
   auto key_ptr = reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(key_lds);
   Ray r;
   r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+  unsigned long long tc_tre = 0, tc_leaf = 0, tc_all = 0, tn_tre = 0, tn_leaf = 0, tn_ray = 0;   // (TRACE)
+  const unsigned long long tc_begin = TRACE ? clock64() : 0ull;
+  auto trace_flush = [&]() {
+    if constexpr (TRACE) {
+      __builtin_amdgcn_s_waitcnt(0);
+      tc_all = clock64() - tc_begin;
+      unsigned long long *const trace_rec = pp->trace == nullptr ? nullptr : pp->trace + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kTraceWords;
+      if (lane == 0 && trace_rec != nullptr) {      // (this wave is the record's only writer; its words 13 .. 15 start at zero)
+        trace_rec[13] += (tc_tre & 0xffffffffffull) | (tn_tre << 40);
+        trace_rec[14] += (tc_leaf & 0xffffffffffull) | (tn_leaf << 40);
+        trace_rec[15] += ((tc_all - tc_tre - tc_leaf) & 0xffffffffffull) | (tn_ray << 40);
+      }
+    }
+  };
+  int cand_j = -1;                 // (per lane) the leaf this lane tested in the bounce's last sphere-test operation, its sphere and colour
+  float4 cand_s = make_float4(0.f, 0.f, 0.f, 1.f), cand_c = make_float4(0.f, 0.f, 0.f, 0.f);
   for (;;) {   // one ray of the pixel's chain per iteration
     ray_derive(r);
+    if (TRACE) tn_ray++;
     unsigned long long key = kKeyInit;
     const float w2 = CULL ? cull_weight(r, cull_c2) : 0.0f;
     if (box_hit(r, rlx, rly, rlz, rhx, rhy, rhz)) {   // (uniform: every lane holds the same ray)
@@ -441,6 +460,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
       int nbox = 1, nleaf = 0;
       while ((nbox | nleaf) != 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned long long tc_op = TRACE ? clock64() : 0ull;
         if (nleaf >= 64 || nbox == 0) {
           // ---- sphere tests: up to 64 leaves ----
           const int top = nleaf - 1 - lane;
@@ -450,11 +470,17 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
           const int jj = act ? ~((int)item >> 8) : 0;
           float4 s = lds_load16(sph_lds + 16u * (unsigned)(jj < lds_sph ? jj : 0));
           if (jj >= lds_sph) s = buf_load16(rs_sph, jj * 16);
+          // (the lane keeps its sphere and fetches the sphere's colour alongside: if this leaf wins the fold, the shading below takes both
+          // from this lane's registers instead of two dependent loads behind the fold -- ~600 cycles of every bounce, round 6)
+          cand_j = act ? jj : -1;
+          cand_c = buf_load16(rs_col, jj * 16);
+          cand_s = s;
           bool near_root;
           const float g = sphere_root_flag(r, s.x, s.y, s.z, s.w, &near_root);
           if (act & (g < kTMax))
             __hip_atomic_fetch_min(key_ptr, ((unsigned long long)__float_as_uint(g) << 32) | ((unsigned)jj << 1) | (near_root ? 1u : 0u),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (TRACE) { __builtin_amdgcn_s_waitcnt(0); tc_leaf += clock64() - tc_op; tn_leaf++; }
         } else {
           // ---- treelet operation (treelet.h, cut of depth kTreeletDepth): up to 64 >> D roots, 2^D lanes each ----
           // lane `pos` of a group reads the record of the treelet's node at that position -- whatever record is there: its
@@ -500,6 +526,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
           lds_store(a_r, (unsigned)cr8);
           nbox = uni(nbox + c_inl + __popcll(m_inr));
           nleaf = uni(nleaf + c_lfl + __popcll(m_lfr));
+          if (TRACE) { __builtin_amdgcn_s_waitcnt(0); tc_tre += clock64() - tc_op; tn_tre++; }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -509,9 +536,19 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
     const float best = __uint_as_float((unsigned)(key >> 32));
     const bool hit = key != kKeyInit;
     const int wj = hit ? (int)((unsigned)key >> 1) : 0;
-    float4 c = buf_load16(rs_col, wj * 16);
-    float4 s = lds_load16(sph_lds + 16u * (unsigned)(wj < lds_sph ? wj : 0));
-    if (wj >= lds_sph) s = buf_load16(rs_sph, wj * 16);
+    float4 c, s;
+    const unsigned long long m_win = bal(hit && cand_j == wj);
+    if (m_win != 0ull) {          // (uniform) a lane of the last sphere-test operation holds the winner's sphere and colour
+      const int src = uni((int)__builtin_ctzll(m_win));
+      auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+      s = make_float4(rl(cand_s.x), rl(cand_s.y), rl(cand_s.z), rl(cand_s.w));
+      c = make_float4(rl(cand_c.x), rl(cand_c.y), rl(cand_c.z), rl(cand_c.w));
+    } else {
+      c = buf_load16(rs_col, wj * 16);
+      s = lds_load16(sph_lds + 16u * (unsigned)(wj < lds_sph ? wj : 0));
+      if (wj >= lds_sph) s = buf_load16(rs_sph, wj * 16);
+    }
+    cand_j = -1;
     if (!hit) {
       s = make_float4(0.f, 0.f, 0.f, 1.f);
       c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -528,6 +565,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
           if (depth >= 2) atomicMax(&pp->cost[ptile], depth + 1);
         }
       }
+      trace_flush();
       return;
     }
   }
@@ -692,7 +730,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
         Ray pr;
         primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
-        solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+        solo_trace<kSoloCull, STATS>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
                    pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, (lrow >> 3) * p.tiles_x + (col >> 3));
       }
     }
@@ -725,7 +763,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
         const int grow = ((k * p.nparts + p.part) << p.rpt_log2) + (lrow & ((1 << p.rpt_log2) - 1));
         Ray pr;
         primary_dir_uv(p.cam, p.u_tab[col], p.v_tab[grow], pr);
-        solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
+        solo_trace<kSoloCull, STATS>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, pr.ox, pr.oy, pr.oz,
                    pr.dx, pr.dy, pr.dz, 1.0f, 1.0f, 1.0f, lrow * p.w + col + k * p.out_skip, 0, tile);
       }
     }
@@ -969,7 +1007,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
                 const int src = uni((int)__builtin_ctzll(m_l));
                 m_l &= m_l - 1ull;
                 auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-                solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
+                solo_trace<kSoloCull, STATS>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, rl(r.ox), rl(r.oy),
                            rl(r.oz), rl(r.dx), rl(r.dy), rl(r.dz), rl(lr), rl(lg), rl(lb), __builtin_amdgcn_readlane(pix, src),
                            __builtin_amdgcn_readlane(depth, src), __builtin_amdgcn_readlane(ptile, src));
               }
@@ -1266,7 +1304,7 @@ __global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
           if (lane == 0) __hip_atomic_store(&wbase[195], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           offered = false;
           __builtin_amdgcn_s_setprio(2);      // (a ray that arrives here is one of the workgroup's last)
-          solo_trace<kSoloCull>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, a.x, a.y, a.z, a.w,
+          solo_trace<kSoloCull, STATS>((KParamsArg)__builtin_amdgcn_kernarg_segment_ptr(), (unsigned)(size_t)smem, (unsigned)(size_t)wbase, a.x, a.y, a.z, a.w,
                      b.x, b.y, b.z, b.w, c.x, __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
           __builtin_amdgcn_s_setprio(0);
           continue;

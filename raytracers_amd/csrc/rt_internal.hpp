@@ -46,6 +46,7 @@ struct rt_context {
   int box2 = 1;             // pooled family: two tree levels per operation for a wave with a nearly empty box stack
   int solo = 1;             // pooled family: a wave left with one ray it cannot add to traces the rest of that pixel in the solo loop
   int treelet = rtk::kTreeletDepth;   // the HOST builder cuts the traversal copy into treelets of this many levels (treelet.h; the GPU builder: always kTreeletDepth; another value switches the solo loop off -- a test aid for the numbering)
+  int trace_solo = 0;       // rt_render_trace: 1 = a list's one-pixel tickets go through solo_trace as in production (its cycle counters: words 13 .. 15 of a wave's record); 0 = through the pooled loop (the record's item counts are then the frame's complete work)
   int trace_part = 0, trace_nparts = 1;   // rt_render_trace: which part of the row-tile partition the instrumented launch renders
   int ray_planes = 0;       // pooled family: planes of the LDS ray table (0 = chosen with the workgroup shape, 2, 3)
   int gpu_build = 1;        // prepare_scene builds the BVH on the GPU (0: host build + upload)
@@ -70,11 +71,11 @@ struct rt_context {
   int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
   int cull = -1;            // pooled family, workgroups of 16 waves: the CULL instantiations -- boxes tested against the slot's best root so far (lane_core.h: cull_limit; same pixels, fewer tests).  -1 (auto): where the scene and the camera pass the proof's guards (rt_host.hpp: CullConst) and the scene is not wholly LDS resident (rgbbox-sized scenes: the walk is short, the tests saved do not pay for the limit's three instructions per item); 1: wherever the guards pass; 0: never
   int eager_sort = 1;       // pooled family: 1 = the sorts that turn a view's record into its tile order and pixel list are launched right behind the recording frame on the context's SECOND stream (they run while the caller synchronises / sets up its next call; the view's next frame -- or a new view that borrows the order -- waits for their event, usually long past); 0 = lazily on the main stream, ahead of the view's next frame (round 5)
-  int borrow = 1;           // pooled family: a NEW view (same image size, partition and bounce limit as a view of this prepared scene already rendered, another camera) renders its first frame through that view's order / pixel list while it records its own -- the order of independent pixels never changes them; the mispredicted long chains are what the DONATE tail is for.  0: a new view's first frame is unordered; 1: through the pixel list where the view could use one of its own, no class holding its wave; 2: through the tile order only; 3: the pixel list with its holds (testing)
+  int borrow = 1;           // pooled family: a NEW view (same image size, partition and bounce limit as a view of this prepared scene already rendered, another camera) renders its first frame through that view's order / pixel list while it records its own -- the order of independent pixels never changes them; the mispredicted long chains are what the DONATE tail is for.  0: a new view's first frame is unordered; 1 (auto): through the other view's pixel list when the scene is read from L2, through its tile order when the scene lives in LDS (api.cpp, measured); 2: the tile order only; 3: the pixel list; 4: the pixel list without its holds (testing)
   int sync_policy = 0;      // 1: a render entry WAITS for the view's class table (deep_policy) instead of polling for it -- which instantiation renders frame k is then the same in every run (measurements, PMC passes); 0: no render entry ever waits for the device
   // ticket counters of the persistent families (rtk::kQueueDwords): all zero between launches -- the last
   // wave of a launch to leave the queue zeroes them (rt_context_sync re-zeroes them after a failed launch)
-  hipStream_t sort_stream = nullptr;   // the second stream (eager_sort): sorts of recorded views
+  hipStream_t sort_stream = nullptr, sort_stream_px = nullptr;   // the sort streams (eager_sort): a recorded view's tile order; its pixel list
   hipEvent_t rec_event = nullptr;      // main stream -> sort stream: "the recording frame has been enqueued up to here"
   unsigned *queue_dev = nullptr;
   int *order_scratch = nullptr;   // the tile-order sort's chunk counts (rtk::kOrderScratchInts), allocated with the first record
@@ -84,12 +85,14 @@ struct rt_context {
   struct UvTable {
     int64_t w, h;
     float *u, *v;
+    size_t bytes = 0;   // of the one block behind both (u first)
   };
   std::vector<UvTable> uv;
   // per-(tile grid) visiting order of a view's FIRST frame (first_order = 1): tile rows, and blocks of 8 tiles inside a row, in bit-reversed order
   struct FirstOrder {
     int tiles_x, tiles_y;
     int *order;   // [rtk::order_table_ints(tiles_x * tiles_y)] a permutation of the tiles, then zeroed class tables
+    size_t bytes;
   };
   std::vector<FirstOrder> first_orders;
   // Freed device blocks kept for the next prepare_scene (the reference's harness prepares the same
@@ -109,6 +112,10 @@ struct rt_context {
   hipEvent_t cams_event = nullptr;   // the last upload from cams_host
   bool cams_event_valid = false;
   rt_group *group = nullptr;   // multi-device context: the devices behind it (multi_gpu.cpp); this context is the first device's
+  // host-pinned landing area of the views' class tables, kClassChunks chunks of kClassSlots x kClassSlotInts ints, one per prepared scene
+  // that has an ordered view (allocated with the context: a hipHostMalloc inside a view's first frames would be timed with them)
+  int *class_slab = nullptr;
+  unsigned long long class_chunks_used = 0;
   char *pinned = nullptr;  // host-pinned block the build kernels report through
   char *stage = nullptr;   // host-pinned staging (kStageBytes) for uploads of small scenes
 };
@@ -134,6 +141,8 @@ struct TileOrder {
   float cam[12];
   int ntiles = 0;
   int nshards = 1;        // shards of the tile queue the table is laid out for (segments + class tables)
+  char *block = nullptr;  // one device block (the context's arena / block pool) behind cost, order, cost_px and px_list
+  size_t block_bytes = 0;
   int *cost = nullptr;    // [ntiles] record written by the render kernel
   int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
@@ -143,8 +152,8 @@ struct TileOrder {
   size_t cost_px_bytes = 0, px_elems = 0;
   bool px_valid = false;
   bool sort_pending = false, sort_px = false;   // the view's last frame recorded its chains; the sorts (tile order; pixel list) are still to be launched
-  hipEvent_t sort_event = nullptr;    // eager_sort: the view's sorts on the context's sort stream ...
-  bool sort_inflight = false;         // ... have been launched and the main stream has not waited for them yet
+  hipEvent_t sort_event = nullptr, sort_event_px = nullptr;    // eager_sort: the view's sorts (tile order; pixel list) on the context's sort streams ...
+  bool sort_inflight = false, sort_inflight_px = false;        // ... have been launched and the main stream has not waited for them yet
   int rec_out_skip = 0;               // ... KParams::out_skip of the recording frame (how cost_px is indexed)
   bool px_solo = false;               // the list was cut with a one-pixel class (the SOLO flavour of the ORD instantiation renders it)
   uint64_t stamp = 0;     // last use (rt_prepared::order_clock)
@@ -157,6 +166,7 @@ struct TileOrder {
   bool classes_pending = false;
 };
 constexpr int kClassSlotInts = 16, kClassSlots = 8;   // per prepared scene: one pinned slot per kept view
+constexpr int kClassChunks = 64;                       // per context: chunks of the pinned slab (prepared scenes with ordered views alive at a time; more: own allocations)
 
 struct rt_prepared {
   mutable std::recursive_mutex mu;   // the views' orders are state of the prepared scene that render entries update: held while a frame is set up
@@ -176,7 +186,8 @@ struct rt_prepared {
   char *block = nullptr;   // one device allocation behind all of the arrays above
   size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-  int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables (allocated with the first ordered view)
+  int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables: a chunk of the context's slab (rt_context::class_slab), or -- slab exhausted -- its own allocation
+  int classes_chunk = -1;            // ... which chunk of the slab (-1: own allocation / none)
   std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
   std::vector<std::future<int>> replica_jobs;   // ... while they are being built (rt_prepare_scene joins them)
 };
@@ -185,6 +196,8 @@ struct rt_prepared {
 namespace rtk {
 // bvh_build.hip: the bit-reversed visiting order of a view's first frame, built on the device (api.cpp: get_first_order)
 hipError_t launch_first_order(int *order, int *rank, int tiles_x, int tiles_y, hipStream_t stream);
+// ... and the u / v tables of an image size (api.cpp: get_uv)
+hipError_t launch_uv_tables(float *u, float *v, int w, int h, hipStream_t stream);
 }
 
 namespace rti {

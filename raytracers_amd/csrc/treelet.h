@@ -34,7 +34,10 @@
 namespace rtk {
 
 constexpr int kTreeletMaxDepth = 5;             // 2^5 - 1 = 31 nodes: positions fit bits 0..30
-constexpr int kTreeletDepth = 2;                // the cut both builders make: a node of even depth + its inner children
+#ifndef RT_TREELET_DEPTH
+#define RT_TREELET_DEPTH 4   // (round 6: 4 levels -- a lone ray's fold is 4 dependent treelet operations instead of 7; 2: rounds 3-5.  -DRT_TREELET_DEPTH=n builds another cut, 1 .. 4)
+#endif
+constexpr int kTreeletDepth = RT_TREELET_DEPTH;   // the cut both builders make: a node whose depth is a multiple of this, and its descendants of relative depth < this
 constexpr uint32_t kTlFrontier = 0x80000000u;   // in mask_l
 constexpr uint32_t kTlPosBits = 0x7fffffffu;
 
@@ -59,24 +62,17 @@ RT_TL_HD TlMasks tl_masks(uint32_t occ, int h, int D) {
   return m;
 }
 
-// The GPU builder (bvh_build.hip) numbers the cut of depth 2 without the general machinery: a node of odd depth sits
-// right behind its parent (position 1, or 2 for a right child whose left sibling is an inner node too).  It carries a
-// node's place next to its traversal index: index in bits 0..26, then odd depth, right child, position (2 bits); bit 31
-// stays clear (the place is also carried in signed ints).  rt_scene_from_spheres admits at most 2^kMaxSpheresLog2 spheres:
-// every inner-node index then fits the index field.
+// The GPU builder (bvh_build.hip) carries a node's place in its treelet next to its traversal index: index in bits 0..26, the node's HEAP
+// index inside its treelet in bits 27..30 (cuts of at most 4 levels: heap index <= 14); bit 31 stays clear (the place is also carried in
+// signed ints).  rt_scene_from_spheres admits at most 2^kMaxSpheresLog2 spheres: every inner-node index then fits the index field.
 constexpr int kMaxSpheresLog2 = 26;
 constexpr int kTlIndexBits = 27;
-static_assert(kTlIndexBits > kMaxSpheresLog2 && kTlIndexBits + 4 <= 31, "a node's place: index field + 4 flag bits in a non-negative int");
+static_assert(kTlIndexBits > kMaxSpheresLog2 && kTlIndexBits + 4 <= 31, "a node's place: index field + 4 bits of heap index in a non-negative int");
+static_assert(kTreeletDepth >= 1 && kTreeletDepth <= 4, "the GPU builder packs a heap index of at most 4 bits");
 constexpr uint32_t kTlIndexMask = (1u << kTlIndexBits) - 1u;
-RT_TL_HD uint32_t tl_pack_place(uint32_t index, bool odd, bool is_right, int pos) {
-  return index | (odd ? 1u << kTlIndexBits : 0u) | (is_right ? 2u << kTlIndexBits : 0u) | ((uint32_t)pos << (kTlIndexBits + 2));
-}
-RT_TL_HD TlMasks tl_masks_depth2(uint32_t place) {   // == tl_masks(occ, heap index, 2) for that node
-  const bool odd = (place >> kTlIndexBits) & 1u, is_right = (place >> (kTlIndexBits + 1)) & 1u;
-  const uint32_t self = 1u << ((place >> (kTlIndexBits + 2)) & 3u);
-  if (!odd) return TlMasks{self, self};
-  return TlMasks{self | (is_right ? 0u : 1u) | kTlFrontier, self | (is_right ? 1u : 0u)};
-}
+RT_TL_HD uint32_t tl_pack_place(uint32_t index, int heap) { return index | ((uint32_t)heap << kTlIndexBits); }
+RT_TL_HD int tl_place_heap(uint32_t place) { return (int)(place >> kTlIndexBits); }
+RT_TL_HD int tl_heap_level(int heap) { return 31 - __builtin_clz((unsigned)heap + 1u); }   // relative depth of a heap index
 
 // kernel side: lane at position `pos` of its group read masks (ml, mr); hl / hr are the group's bits (bit p = the lane at
 // position p found the box of its node's left / right child passing).  true: this lane holds a node of the item's

@@ -180,6 +180,11 @@ class ShardedStep:
         dist.all_gather_object(oks, (ok, err), group=self.group)
         if not all(o for o, _ in oks):
             self.exchange_note = "direct stores unavailable (" + "; ".join(e for o, e in oks if not o) + "): gather"
+            # the ranks that DID map rank dst's buffer unmap it before its owner frees it (the order close() keeps): every rank
+            # is here -- the all-gather above was collective -- so the barrier is too
+            if self.rank != self.dst:
+                self._release_direct()
+            dist.barrier(group=self.group)
             self._release_direct()
             return False
         self.exchange_mode = "direct"

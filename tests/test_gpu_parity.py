@@ -235,7 +235,7 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
                                   dict(pixel_order=2, solo=0), dict(pixel_order=2, grid_div=16, px_solo_div=1),
                                   dict(pixel_order=2, px_g1=1, px_g8=2, px_g16=3, px_g32=4, px_g64=5, px_ray_ns=1),
                                   dict(pixel_order=2, px_g1=1000, px_g64=20000, px_ray_ns=20000, thr_shade=8),
-                                  dict(pixel_order=2, gpu_build=0, treelet=4), dict(pixel_order=2, xcd_queues=1)])
+                                  dict(pixel_order=2, gpu_build=0, treelet=2), dict(pixel_order=2, xcd_queues=1)])
 def test_pixel_tickets(R, opts):
     """Ordered single frames that draw their tickets from the view's PIXEL LIST (the first frame records every pixel's
     chain length, the sorts run ahead of the second frame, the ORD instantiation renders from it): the list's classes cut by the device's
@@ -463,7 +463,7 @@ def test_first_frames_of_new_views(R, opts):
     c.close()
 
 
-@pytest.mark.parametrize("treelet", [1, 3, 4, 5])
+@pytest.mark.parametrize("treelet", [1, 2, 3, 5])
 def test_host_builder_other_treelet_cuts(R, treelet):
     """The host builder's numbering under other cuts than the shipped one (treelet.h; the solo loop is off then): the
     pooled loop does not care how the traversal copy is numbered."""
@@ -634,7 +634,7 @@ def test_camera_path_one_frame_at_a_time(R, scene, h, w):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(eager_sort=0), dict(borrow=0), dict(borrow=0, eager_sort=0), dict(pixel_order=0), dict(pixel_order=2, handover=2, donate_max=8),
-                                  dict(handover=0), dict(cull=1), dict(solo=0, thr_shade=8), dict(gpu_build=0, treelet=4), dict(xcd_queues=0, static_first=0), dict(adaptive_order=2)])
+                                  dict(handover=0), dict(cull=1), dict(solo=0, thr_shade=8), dict(gpu_build=0, treelet=2), dict(xcd_queues=0, static_first=0), dict(adaptive_order=2)])
 def test_new_views_borrow_the_previous_views_order(R, opts):
     """Round 6: a NEW view of a prepared scene (another camera, same image size / partition) renders its first frame through the order /
     pixel list of the view rendered last (`borrow`), with the DONATE tail for the chains that list places wrongly (the ORD + DONATE

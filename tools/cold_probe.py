@@ -66,7 +66,22 @@ for spec in sets:
             torch.cuda.synchronize()
             per.append(a.elapsed_time(b))
         ps.free()
+        # ... and the same path enqueued back to back, one sync at the end (what bench.py's camera_path_frame_by_frame_ms measures)
+        ps = R.prepare_scene(h, w, sc)
+        nb2 = 20
+        cams2 = np.tile(np.asarray(ps.camera(), dtype=np.float32).reshape(1, 12), (nb2, 1))
+        cams2[:, 0] += 0.05 * np.arange(nb2, dtype=np.float32)
+        cams2[:, 3] += 0.05 * np.arange(nb2, dtype=np.float32)
+        evb = [torch.cuda.Event(enable_timing=True) for _ in range(nb2 + 1)]
+        torch.cuda.synchronize()
+        evb[0].record()
+        for f in range(nb2):
+            R.render_into(img.data_ptr(), h, w, ps, cam=cams2[f])
+            evb[f + 1].record()
+        torch.cuda.synchronize()
+        b2b = [evb[f].elapsed_time(evb[f + 1]) for f in range(nb2)]
+        ps.free()
         print(f"[{spec}] {scene} {w}x{h}: first frame min {min(first):.3f} median {np.median(first):.3f} ms; second {np.median(second):.3f}; "
-              f"camera path view by view: first {per[0]:.3f}, mean of the rest {np.mean(per[1:]):.3f} ms", flush=True)
+              f"camera path view by view: first {per[0]:.3f}, mean of the rest {np.mean(per[1:]):.3f} ms; back to back (no sync): first {b2b[0]:.3f}, mean of the rest {np.mean(b2b[1:]):.3f} ms", flush=True)
         warm.free()
     ctx.close()

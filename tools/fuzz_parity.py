@@ -64,7 +64,7 @@ while time.time() < t_end:
                  xcd_queues=int(rng.choice([-1, 0, 1, 2])), tpt_log2=int(rng.choice([-1, -1, 0, 1, 2, 3, 4])),
                  static_first=int(rng.choice([0, 1, 1])),
                  # the host builder's treelet cut (another cut than the shipped one switches the solo loop off)
-                 treelet=int(rng.choice([2, 2, 2, 1, 4])),
+                 treelet=int(rng.choice([4, 4, 4, 1, 2, 3])),
                  # the tails of single frames: 1 = DONATE for unordered frames (rays of waves that cannot refill go to waiting sibling
                  # waves) and COLD for small ordered ones (in-loop hand-over to the solo loop), 2 = DONATE for every single frame
                  handover=int(rng.choice([0, 1, 1, 2, 2])), donate_max=int(rng.choice([1, 4, 64])), look_max=int(rng.choice([0, 0, 1, 16, 32, 64])),

@@ -60,3 +60,20 @@ for i in late[::-1]:
     print(f"    wave {i:5d}: start {start[i]:7.1f} exhausted {exh[i]:7.1f} end {end[i]:7.1f} us; ops {tot[i]:6d} (box {ops[i,0]} leaf {ops[i,1]} shade {ops[i,2]}) deepest chain {rec[i,7]}")
     print(f"                cycles/op: {per}; between ops {(rec[i, 4] - cyc[i].sum()) / max(tot[i], 1):.0f}")
 print(f"  drain phase (exhausted -> end): mean {np.mean(end - exh):.1f} max {np.max(end - exh):.1f} us")
+# option trace_solo=1: the solo loop's own counters (words 13 .. 15): cycles inside treelet operations / sphere-test operations / the rest of a
+# bounce (ray_derive, root box, the winner's loads, shade), with their counts
+M40 = (1 << 40) - 1
+s_tre, n_tre, s_leaf, n_leaf, s_rest, n_ray = rec[:, 13] & M40, rec[:, 13] >> 40, rec[:, 14] & M40, rec[:, 14] >> 40, rec[:, 15] & M40, rec[:, 15] >> 40
+if n_ray.sum() > 0:
+    mhz = float(np.mean(rec[:, 4] / np.maximum(life_us, 0.01)))
+    w = n_ray > 0
+    per_bounce = (s_tre + s_leaf + s_rest)[w] / n_ray[w]
+    print(f"  SOLO loop ({int(w.sum())} waves, {int(n_ray.sum())} rays): per ray {n_tre.sum() / n_ray.sum():.2f} treelet operations x {s_tre.sum() / max(n_tre.sum(), 1):.0f} cycles, "
+          f"{n_leaf.sum() / n_ray.sum():.2f} sphere-test operations x {s_leaf.sum() / max(n_leaf.sum(), 1):.0f}, the rest of a bounce {s_rest.sum() / n_ray.sum():.0f} cycles")
+    print(f"    cycles per bounce over the waves: mean {per_bounce.mean():.0f} p50 {np.median(per_bounce):.0f} p95 {np.percentile(per_bounce, 95):.0f} max {per_bounce.max():.0f}"
+          f"  = {per_bounce.mean() / mhz:.2f} / {np.median(per_bounce) / mhz:.2f} / {np.percentile(per_bounce, 95) / mhz:.2f} / {per_bounce.max() / mhz:.2f} us at {mhz:.0f} MHz")
+    deep = np.argsort(n_ray)[-5:][::-1]
+    for i in deep:
+        if n_ray[i]:
+            print(f"    wave {i:5d}: {n_ray[i]} rays in the solo loop: treelet {s_tre[i] / max(n_tre[i], 1):.0f} x {n_tre[i] / n_ray[i]:.1f}, sphere {s_leaf[i] / max(n_leaf[i], 1):.0f} x {n_leaf[i] / n_ray[i]:.1f}, "
+                  f"rest {s_rest[i] / n_ray[i]:.0f}: {(s_tre[i] + s_leaf[i] + s_rest[i]) / n_ray[i]:.0f} cycles per bounce")
