@@ -73,8 +73,9 @@ const char *rt_last_error(const rt_context *ctx);       /* "" when no error; own
  *   "family=none (no rows)"       the part owns no row of the image
  *   "family=pixel" | "family=pixel (instrumented)" | "family=persistent"
  *   "family=pooled tickets=T instantiation=I[+CULL] frames=.. tiles=.. grid=.. waves=.. counters=..[(turns)] deep_class=.. deep_split=.. recording=0|1|2"
- *     T = pixel-list | tiles-ordered | tiles-bit-reversed (a view's first frame, first_order = 1) | tiles-raster
- *     I = plain | SOLO | COLD | COLD+SOLO | DONATE | DONATE+SOLO | ORD | ORD+SOLO;  +CULL: boxes tested against the best hit so far
+ *     T = pixel-list | tiles-ordered | tiles-bit-reversed (a view's first frame with nothing to borrow, first_order = 1) | tiles-raster,
+ *         followed by "(borrowed)" when the order / list is another view's (a new view of a prepared scene that has rendered a view of the same shape)
+ *     I = plain | SOLO | COLD | COLD+SOLO | DONATE | DONATE+SOLO | ORD | ORD+SOLO | ORD+DONATE | ORD+SOLO+DONATE;  +CULL: boxes tested against the best hit so far
  *     recording: 0 nothing, 1 the tiles' longest chains, 2 also every pixel's chain length */
 const char *rt_context_last_launch(const rt_context *ctx);
 int rt_context_sync(rt_context *ctx);

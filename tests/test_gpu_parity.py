@@ -1470,6 +1470,29 @@ def test_render_entries_never_wait_for_the_device(R):
 
 
 # ---------------------------------------------------------------- error behaviour ---------
+def test_sync_policy_makes_the_instantiation_reproducible(R):
+    """Option sync_policy = 1 (measurements, PMC passes): a render entry waits for the view's class table instead of polling for it, so
+    which instantiation renders frame k of a view does not depend on when a copy lands -- two contexts, the same call sequence through
+    the tile-ticket path (pixel_order = 0, the only reader of the table), the same rt_context_last_launch frame by frame; pixels exact."""
+    seqs = []
+    for rep in range(2):
+        c = R.Context()
+        c.set_variant(3)
+        c.set_option("sync_policy", 1)
+        c.set_option("pixel_order", 0)
+        ps = R.prepare_scene(500, 500, c.scene("irreg"))
+        want, _ = _oracle("irreg").render(500, 500)
+        seq = []
+        for frame in range(5):
+            assert int((R.render(500, 500, ps) != want).sum()) == 0, frame
+            seq.append(c.last_launch)
+        seqs.append(seq)
+        ps.free()
+        c.close()
+    assert seqs[0] == seqs[1], seqs
+    assert "deep_split=6" in seqs[0][-1] or "SOLO" in seqs[0][-1], seqs[0]   # (the policy did arrive: irreg's deep tiles go out pixel by pixel)
+
+
 def test_errors_are_codes_with_messages(R, ctx):
     """Every entry returns non-zero on failure and leaves a message (the reference's harness
     convention is `assert(ret == 0)`, futhark/main.c:74,97,116,131); nothing is written then."""

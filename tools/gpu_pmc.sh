@@ -22,7 +22,7 @@ for s in $SCENES; do for gd in $GDS; do
   [ "$gd" != "0" ] && np=2        # other launch sizes: instruction counts and LDS cycles only
   for ((i = 0; i < np; i++)); do
     d=$OUT/${s}_gd${gd}_p${i}
-    timeout 300 rocprofv3 --pmc ${PASSES[$i]} --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s $s -n 1000 -m 1000 -r 8 -v 3 $([ "$gd" = "0" ] || echo "-o grid_div=$gd -o deep_class=0") > $d.log 2>&1
+    timeout 300 rocprofv3 --pmc ${PASSES[$i]} --kernel-trace --output-format csv -d $d -- $OLDPWD/build/rtbench -s $s -n 1000 -m 1000 -r 8 -v 3 -o sync_policy=1 $([ "$gd" = "0" ] || echo "-o grid_div=$gd -o deep_class=0") > $d.log 2>&1
   done
 done
 # batch launches (rt_render_batch, what bench.py times): 20 frames per launch, batch-only mode of rtbench
