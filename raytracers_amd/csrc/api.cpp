@@ -325,6 +325,7 @@ int request_classes(rt_context *ctx, const rt_prepared *ps_c, TileOrder *to, hip
       if (!(ctx->class_chunks_used >> c & 1ull)) {
         ctx->class_chunks_used |= 1ull << c;
         ps->classes_chunk = c;
+        ps->classes_owner = ctx;
         ps->classes_pinned = ctx->class_slab + static_cast<size_t>(c) * kClassSlotInts * kClassSlots;
       }
     if (!ps->classes_pinned)
@@ -417,6 +418,22 @@ int await_view(rt_context *ctx, TileOrder *v) {
   }
   return 0;
 }
+void drain_streams(rt_context *ctx);
+// a view's block back to where it came from: its home context's arena / pool (under that context's lock when it is not the caller's), or hipFree.
+// The caller has drained its own streams.
+void free_view_block(rt_context *ctx, TileOrder &v) {
+  if (!v.block) return;
+  if (!v.block_owner) {
+    (void)hipFree(v.block);
+  } else if (v.block_owner == ctx) {
+    pool_free(ctx, v.block, v.block_bytes);
+  } else {
+    RT_LOCK(v.block_owner);
+    drain_streams(v.block_owner);
+    pool_free(v.block_owner, v.block, v.block_bytes);
+  }
+  v.block = nullptr;
+}
 // have the view's sorts finished on the device?  (never blocks; clears the in-flight flags when they have: nothing needs to wait any more)
 bool sorts_complete(TileOrder *v) {
   if (v->sort_inflight) {
@@ -465,6 +482,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   if (rows_per_tile <= 0 || nparts <= 0 || part < 0 || part >= nparts) return fail(ctx, "bad row-tile partition");
   if (max_depth < 0) return fail(ctx, "negative max_depth");
   RT_HIP(ctx, hipSetDevice(ctx->device));
+  (void)hipGetLastError();   // (the launchers below read the thread's last error right behind their launches: an earlier call's leftover is not theirs)
   rtk::KParams p{};
   p.nodes = ps->nodes; p.nodes64 = ps->nodes64; p.sph = ps->sph; p.col = ps->col;
   std::copy(ps->root_lo, ps->root_lo + 3, p.root_lo);
@@ -612,9 +630,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
           if (v.block_bytes >= need_bytes) {       // the evicted view's block as it is
             o.block = v.block;
             o.block_bytes = v.block_bytes;
+            o.block_owner = v.block_owner;
           } else {
             drain_streams(ctx);
-            pool_free(ctx, v.block, v.block_bytes);
+            free_view_block(ctx, v);
           }
           ps->orders.erase(ps->orders.begin() + static_cast<std::ptrdiff_t>(lru));
         }
@@ -626,7 +645,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
         // cost the reference's harness ~0.3 ms of its first frame)
         if (!o.block) {
           o.block_bytes = need_bytes;
-          RT_HIP(ctx, pool_alloc(ctx, &o.block, &o.block_bytes));
+          if (ctx == ps->home) {
+            RT_HIP(ctx, pool_alloc(ctx, &o.block, &o.block_bytes));
+            o.block_owner = ctx;
+          } else {      // (rendered through another context than the one that prepared the scene: no arena of ours to take it from)
+            RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&o.block), o.block_bytes));
+          }
         }
         o.cost = reinterpret_cast<int *>(o.block);
         o.order = reinterpret_cast<int *>(o.block + off_order);
@@ -649,27 +673,20 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // frames -- which were unordered (tiles in bit-reversed order, DONATE tail).  Neighbouring views agree on WHERE the long chains
       // are (they cluster at the walls' edges / at grazing angles, profiles/r04/README.md) even though single pixels do not; the
       // chains the borrowed list places wrongly are what the DONATE tail catches.  Only the order of independent pixels changes.
-      // WHICH view: the most recently rendered one whose sorts have COMPLETED (an event query: nothing waits) -- a caller that synchronises
-      // after every frame finds the view before the previous one there, the previous view's sorts still running.  If none has: the second
-      // most recent one (a caller that enqueues its frames back to back: the most recent view's sorts cannot start before its frame ends,
-      // and this frame would wait for both -- the camera path of the bench, frame by frame without a sync: 0.52 ms per frame that way,
-      // 0.49 unordered), else the most recent one (the second view of a path: waiting ~0.05 ms for its sorts beats rendering unordered).
+      // WHICH view: one of the two views rendered before this one whose sorts are THROUGH on the device (an event query: a borrowed frame never
+      // waits for anything) -- a caller that synchronises after every frame finds the previous view there, or the one before it.  A caller
+      // that enqueues new views back to back is far ahead of the device, finds none and renders unordered as before: waiting for sorts that
+      // cannot start before their frame ends serialises frame, sorts, frame, and measured 0.45-0.54 ms per irreg 1000 x 1000 view against
+      // 0.43 unordered, from run to run; an OLDER sorted view predicts worse than no order at all (0.54).  (sync_policy = 1: the most recent
+      // view whatever its state, behind a stream wait -- the same launches in every run, for tests and measurements; eager_sort = 0: the
+      // pending sorts run in line, which waits for nothing either.)
       if (!use && ctx->borrow && nframes == 1 && ctx->adaptive_order == 1) {
-        TileOrder *done = nullptr, *fl1 = nullptr, *fl2 = nullptr;
+        TileOrder *from = nullptr;
         for (auto &o : ps->orders) {
           if (&o == to || !same_shape(o) || !(o.valid || o.sort_pending)) continue;
-          if (!o.sort_pending && sorts_complete(&o)) {
-            if (!done || o.stamp > done->stamp) done = &o;
-          } else if (!fl1 || o.stamp > fl1->stamp) {
-            fl2 = fl1;
-            fl1 = &o;
-          } else if (!fl2 || o.stamp > fl2->stamp) {
-            fl2 = &o;
-          }
+          const bool ok = ctx->sync_policy ? true : (o.stamp + 2 >= to->stamp && (o.sort_pending ? !ctx->eager_sort : sorts_complete(&o)));
+          if (ok && (!from || o.stamp > from->stamp)) from = &o;
         }
-        // (the most recent of {a view whose sorts are through, the second most recent view still being sorted}; the most recent view still
-        // being sorted only if there is nothing else: a caller far ahead of the device would otherwise borrow from a view many frames back)
-        TileOrder *from = (done && fl2) ? (done->stamp > fl2->stamp ? done : fl2) : (done ? done : (fl2 ? fl2 : fl1));
         if (from) {
           if (int rc = sort_view(ctx, ps, from, p, pl)) return rc;
           use = from;
@@ -1109,9 +1126,11 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
   if (h <= 0 || w <= 0) return fail(ctx, "image size must be positive");
   if (scene->desc.spheres.size() < 2) return fail(ctx, "scene needs at least 2 spheres");
   RT_HIP(ctx, hipSetDevice(ctx->device));
+  (void)hipGetLastError();   // (as in enqueue_render)
   auto ps = std::make_unique<rt_prepared>();
   const size_t n = scene->desc.spheres.size(), ni = n - 1;
   ps->n = static_cast<int64_t>(n);
+  ps->home = ctx;
   ps->h = h; ps->w = w;
   ps->cam = rt::scene_camera(scene->desc, h, w);
   int rc = 0;
@@ -1241,13 +1260,13 @@ extern "C" int rt_prepared_free(rt_context *ctx, rt_prepared *ps) {
   }
   pool_free(ctx, ps->block, ps->block_bytes);
   for (auto &o : ps->orders) {
-    pool_free(ctx, o.block, o.block_bytes);
+    free_view_block(ctx, o);
     if (o.classes_event) (void)hipEventDestroy(o.classes_event);
     if (o.sort_event) (void)hipEventDestroy(o.sort_event);
     if (o.sort_event_px) (void)hipEventDestroy(o.sort_event_px);
   }
   if (ps->classes_pinned && ps->classes_chunk < 0) (void)hipHostFree(ps->classes_pinned);
-  if (ps->classes_chunk >= 0 && ctx) ctx->class_chunks_used &= ~(1ull << ps->classes_chunk);
+  if (ps->classes_chunk >= 0 && ps->classes_owner) ps->classes_owner->class_chunks_used &= ~(1ull << ps->classes_chunk);
   delete ps;
   return 0;
 }

@@ -141,8 +141,9 @@ struct TileOrder {
   float cam[12];
   int ntiles = 0;
   int nshards = 1;        // shards of the tile queue the table is laid out for (segments + class tables)
-  char *block = nullptr;  // one device block (the context's arena / block pool) behind cost, order, cost_px and px_list
+  char *block = nullptr;  // one device block (a context's arena / block pool) behind cost, order, cost_px and px_list ...
   size_t block_bytes = 0;
+  rt_context *block_owner = nullptr;   // ... and the context whose arena it came from: the prepared scene's home context, or nullptr = a plain hipMalloc (a frame rendered through another context -- a multi-device context's first child renders the parent's prepared scene)
   int *cost = nullptr;    // [ntiles] record written by the render kernel
   int *order = nullptr;   // [rtk::order_table_ints(ntiles)] position -> tile table for the next frames, then the shards' class tables
   bool valid = false;     // order[] has been computed from a previous frame
@@ -169,6 +170,7 @@ constexpr int kClassSlotInts = 16, kClassSlots = 8;   // per prepared scene: one
 constexpr int kClassChunks = 64;                       // per context: chunks of the pinned slab (prepared scenes with ordered views alive at a time; more: own allocations)
 
 struct rt_prepared {
+  rt_context *home = nullptr;        // the context that prepared it (its arena serves the views' blocks when it also renders them)
   mutable std::recursive_mutex mu;   // the views' orders are state of the prepared scene that render entries update: held while a frame is set up
   mutable std::vector<TileOrder> orders;
   mutable uint64_t order_clock = 0;
@@ -187,7 +189,8 @@ struct rt_prepared {
   size_t block_bytes = 0;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   int *classes_pinned = nullptr;     // [kClassSlots][kClassSlotInts] host-pinned landing area of the views' class tables: a chunk of the context's slab (rt_context::class_slab), or -- slab exhausted -- its own allocation
-  int classes_chunk = -1;            // ... which chunk of the slab (-1: own allocation / none)
+  int classes_chunk = -1;            // ... which chunk of the slab (-1: own allocation / none) ...
+  rt_context *classes_owner = nullptr;   // ... of which context
   std::vector<rt_prepared *> replicas;   // multi-device context: [i] = the scene prepared on device i (i >= 1; [0] unused)
   std::vector<std::future<int>> replica_jobs;   // ... while they are being built (rt_prepare_scene joins them)
 };
