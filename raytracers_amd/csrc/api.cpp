@@ -785,6 +785,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.cull_c2 = ps->cull.c2;
       p.cull_kappa = ps->cull.kappa;
     }
+    // (a recording frame: was the stream idle when this call came in?  Then the caller synchronises between its frames and the record's sorts can
+    // run behind the frame while it does; a caller that enqueues frames back to back gets them lazily, ahead of the view's next frame, as in
+    // round 5 -- sorts squeezed in between its frames cost it 0.03-0.07 ms per new view and it may never render the view again)
+    bool stream_was_idle = false;
+    if (to && p.cost && ctx->eager_sort) {
+      stream_was_idle = hipStreamQuery(ctx->stream) == hipSuccess;
+      (void)hipGetLastError();
+    }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     {
       // (which instantiation launch_pooled picks, in its own order of precedence)
@@ -808,7 +816,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // (eager_sort, the default: ... but they are LAUNCHED here, on the context's second stream, behind this frame: they run while the caller
       // synchronises and sets up its next call, off every frame's critical path -- the view's second frame no longer carries them, and a
       // new view can borrow this one's order at once)
-      if (ctx->eager_sort)
+      if (ctx->eager_sort && (stream_was_idle || ctx->sync_policy))
         if (int rc = sort_view(ctx, ps, to, p, pl)) return rc;
     }
   }
