@@ -619,6 +619,24 @@ def main():
         serial = timed(nser, 0)
         n_verified += verify([serial_lane], "serial region,")
         serial_launch = {f"{sc}_{w}x{h}": pr.ctx.last_launch for (sc, h, w), pr in zip(frames, serial_lane.prs)}   # which kernel rendered them
+        # Culling by the best hit (the CULL instantiations): the sphere tests the PRODUCT's launch actually makes, from an
+        # instrumented launch of the same view (rt_render_trace: leaf items over all waves).  The reference's count (FRAME_WORK, what
+        # alg_bytes is defined on) is an upper bound; pixels are verified above.
+        culled_work = {}
+        if world == 1 and rank == 0:
+            import ctypes as C
+            from raytracers_amd._lib import lib as _rtlib
+            for (sc, h, w), pr in zip(frames, serial_lane.prs):
+                if "+CULL" not in serial_launch[f"{sc}_{w}x{h}"]:
+                    continue
+                rec = np.zeros((8192, 16), dtype=np.uint64)
+                nw = C.c_int32()
+                if _rtlib.rt_render_trace(pr.ctx._h, pr.prepared._h, h, w, 50, rec.ctypes.data, 8192, C.byref(nw)) == 0:
+                    made = int((rec[: nw.value, 6].astype(np.int64) & 0xFFFFFFFF).sum())
+                    ref_t = work[(sc, h, w)][2]
+                    if made > ref_t:
+                        raise SystemExit(f"culled launch of {sc} {w}x{h} made MORE sphere tests ({made}) than the reference's fold ({ref_t})")
+                    culled_work[f"{sc}_{w}x{h}"] = {"sphere_tests_made": made, "sphere_tests_reference": ref_t, "saved": 1.0 - made / ref_t}
 
     # The FIRST frames of a view (the reference's `render` is stateless, ray.fut:246; here the tile order, the deep-tile
     # policy and the solo pixels exist from a view's second frame on) and a camera path (a batch with a camera per frame
@@ -854,6 +872,7 @@ def main():
                 "note": "the reference's protocol: one frame at a time on one stream (futhark/main.c:107-124), library-default "
                         "knobs, measured right after the timed region; kernel_ms = HIP events around each launch",
                 "launch": serial_launch,
+                **({"culled_work": culled_work} if culled_work else {}),
                 "value": out["serial_value"], "ms_per_step": sdt / nser * 1e3, "kernel_ms": out["serial_ms_per_frame"],
                 "alg_bytes_GBs": {f"{sc}_{w}x{h}": bytes_alg(work[(sc, h, w)][1], work[(sc, h, w)][2], h, w) / world
                                   / (skms[i] * 1e-3) / 1e9 for i, (sc, h, w) in enumerate(frames)}}
