@@ -483,6 +483,16 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   if (max_depth < 0) return fail(ctx, "negative max_depth");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   (void)hipGetLastError();   // (the launchers below read the thread's last error right behind their launches: an earlier call's leftover is not theirs)
+  // Does this caller synchronise between its frames?  It called rt_context_sync (futhark_context_sync: the completion point of the ABI) since
+  // its last render entry, or the stream is idle right now.  Then a recording frame's sorts are launched behind the frame and run while
+  // the caller synchronises; a caller that enqueues frames back to back gets them lazily, ahead of the view's next frame, as in round 5 --
+  // sorts squeezed in between its frames cost it 0.03-0.07 ms per new view, and it may never render the view again.
+  bool stream_was_idle = ctx->synced_since_render;
+  ctx->synced_since_render = false;
+  if (!stream_was_idle && ctx->eager_sort && nframes == 1) {
+    stream_was_idle = hipStreamQuery(ctx->stream) == hipSuccess;
+    (void)hipGetLastError();
+  }
   rtk::KParams p{};
   p.nodes = ps->nodes; p.nodes64 = ps->nodes64; p.sph = ps->sph; p.col = ps->col;
   std::copy(ps->root_lo, ps->root_lo + 3, p.root_lo);
@@ -785,14 +795,6 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.cull_c2 = ps->cull.c2;
       p.cull_kappa = ps->cull.kappa;
     }
-    // (a recording frame: was the stream idle when this call came in?  Then the caller synchronises between its frames and the record's sorts can
-    // run behind the frame while it does; a caller that enqueues frames back to back gets them lazily, ahead of the view's next frame, as in
-    // round 5 -- sorts squeezed in between its frames cost it 0.03-0.07 ms per new view and it may never render the view again)
-    bool stream_was_idle = false;
-    if (to && p.cost && ctx->eager_sort) {
-      stream_was_idle = hipStreamQuery(ctx->stream) == hipSuccess;
-      (void)hipGetLastError();
-    }
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
     {
       // (which instantiation launch_pooled picks, in its own order of precedence)
@@ -933,7 +935,11 @@ extern "C" const char *rt_context_last_launch(const rt_context *ctx) { return ct
 extern "C" int rt_context_sync(rt_context *ctx) {
   RT_LOCK(ctx);
   if (!ctx) return 1;
-  if (ctx->group) return rti::group_sync(ctx);   // every frame ends on the parent's stream, synchronised last
+  if (ctx->group) {   // every frame ends on the parent's stream, synchronised last
+    const int grc = rti::group_sync(ctx);
+    if (!grc) rti::group_mark_synced(ctx);
+    return grc;
+  }
   // Frames take well under a millisecond: poll briefly (a frame's worth) before falling back to the
   // blocking wait, whose wake-up latency alone is a sizeable fraction of a frame.  The poll is short on
   // purpose: a process with many contexts must not burn a host core per context.
@@ -947,7 +953,10 @@ extern "C" int rt_context_sync(rt_context *ctx) {
       break;
     }
   }
-  if (q == hipSuccess) return 0;
+  if (q == hipSuccess) {
+    ctx->synced_since_render = true;
+    return 0;
+  }
   // A launch that died leaves the ticket counters non-zero (its last wave never zeroed them): every later
   // frame would draw out-of-range tickets and silently render nothing.  Re-zero them.
   (void)hipGetLastError();
@@ -1678,6 +1687,7 @@ extern "C" int rt_copy_to_host(rt_context *ctx, void *dst_host, const void *src_
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->synced_since_render = true;
   return 0;
 }
 

@@ -235,6 +235,10 @@ int rti::group_sync(rt_context *ctx) {
   return 0;
 }
 
+void rti::group_mark_synced(rt_context *ctx) {
+  for (rt_context *kid : ctx->group->kids) kid->synced_since_render = true;
+}
+
 int rti::group_set_variant(rt_context *ctx, int variant) {
   for (rt_context *kid : ctx->group->kids)
     if (rt_context_set_variant(kid, variant)) return fail(ctx, rt_last_error(kid));

@@ -27,6 +27,7 @@ struct rt_context {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  bool synced_since_render = true;   // the caller has synchronised the context (rt_context_sync, rt_copy_to_host) since its last render entry: it syncs between frames
   std::string last_launch;  // what the last render entry enqueued (rt_context_last_launch): family, tickets, instantiation, launch shape
   int num_cu = 0;
   int lds_bytes = 0;
@@ -221,6 +222,7 @@ void group_prepare_begin(rt_context *ctx, rt_prepared *ps, int64_t h, int64_t w,
 int group_prepare_end(rt_context *ctx, rt_prepared *ps);                                                    // joins them
 void group_prepared_free(rt_context *ctx, rt_prepared *ps);
 int group_sync(rt_context *ctx);
+void group_mark_synced(rt_context *ctx);   // the children of a multi-device context: the caller has synchronised
 int group_set_variant(rt_context *ctx, int variant);
 int group_set_option(rt_context *ctx, const char *name, int64_t value);
 void group_destroy(rt_context *ctx);
