@@ -644,7 +644,7 @@ def main():
     cold = None
     if serial_lane is not None and world == 1 and rank == 0:
         import raytracers_amd as R
-        first, first_wall, path, path_serial, path_b2b = {}, {}, {}, {}, {}
+        first, first_wall, path, path_serial, path_b2b, path_rb = {}, {}, {}, {}, {}, {}
         for (scene, h, w), pr in zip(frames, serial_lane.prs):
             img = torch.empty((h, w), dtype=torch.int32, device=device)
             want = FRAME_CHECKSUM.get((scene, h, w))
@@ -705,6 +705,22 @@ def main():
                 raise SystemExit(f"VERIFICATION FAILED: camera path (view by view) of {scene} {w}x{h}")
             path_serial[f"{scene}_{w}x{h}"] = {"first": per[0], "mean_of_the_rest": float(np.mean(per[1:]))}
             ps3.free()
+            # ... view by view with the frame READ BACK after every render (futhark_values_i32_2d: what a consumer of the frames does; the harness
+            # with -f): the device idles ~0.3 ms per view, the previous view's sorts finish in that gap, the new view borrows its order.
+            # Kernel time of the render per view (events), the copy excluded.
+            ps3 = R.prepare_scene(h, w, pr.scene)
+            host = torch.empty((h, w), dtype=torch.int32).pin_memory()
+            evr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nb)]
+            for f in range(nb):
+                evr[f][0].record()
+                R.render_into(img.data_ptr(), h, w, ps3, cam=cams[f])
+                evr[f][1].record()
+                pr.ctx.sync()
+                host.copy_(img)
+                torch.cuda.synchronize()
+            per = [a.elapsed_time(b) for a, b in evr]
+            path_rb[f"{scene}_{w}x{h}"] = {"first": per[0], "mean_of_the_rest": float(np.mean(per[1:])), "last_launch": pr.ctx.last_launch}
+            ps3.free()
             # ... and enqueued back to back, one sync at the end (the caller is far ahead of the device: nothing a new view could borrow is sorted yet)
             ps3 = R.prepare_scene(h, w, pr.scene)
             evp = [torch.cuda.Event(enable_timing=True) for _ in range(nb + 1)]
@@ -730,8 +746,13 @@ def main():
                                     "frame checked against single renders of the same cameras",
                 "camera_path_frame_by_frame_ms": path_serial,
                 "camera_path_frame_by_frame_note": "the same 20 cameras one view at a time on a fresh prepared scene, render + sync per view as the reference's harness "
-                                                   "does (main.c:113-117), wall clock: every view is new; from the third on it renders through the order / pixel list "
-                                                   "of one of the two views before it (borrow) while it records its own",
+                                                   "does (main.c:113-117), wall clock: every view is new.  A new view borrows the order of one of the two views before "
+                                                   "it only if that view's sorts are THROUGH when the call comes in -- with no gap between sync and the next render "
+                                                   "they are not (they need ~0.1 ms of an idle device), so these views render unordered, as in round 5",
+                "camera_path_with_readback_ms": path_rb,
+                "camera_path_with_readback_note": "the same views, render + sync + a 4 MB device-to-host copy of the frame per view (what a consumer of the frames does): "
+                                                  "kernel time of the render per view (events; the copy excluded).  The device idles during the copy, the previous view's "
+                                                  "sorts finish in that gap, and the new view renders through the borrowed order (last_launch says so)",
                 "camera_path_back_to_back_ms": path_b2b,
                 "camera_path_back_to_back_note": "the same views enqueued back to back, one sync at the end (events between the calls): the caller is far ahead of the "
                                                  "device, no earlier view's sorts are through when a new view is enqueued, every view renders unordered"}

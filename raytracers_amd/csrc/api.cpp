@@ -377,7 +377,9 @@ int sort_view(rt_context *ctx, const rt_prepared *ps, TileOrder *v, const rtk::K
     for (int k = 0; k < 4; ++k) pol.thr[k] = ctx->px_thr[k];
     // the model's bounce cadences (0.1 us; measured, profiles/r05/README.md): a scene that lives in LDS, one that is read from L2
     const bool whole_scene = pl.lds_nodes == static_cast<int>(ps->n - 1) && pl.lds_sph == static_cast<int>(ps->n);
-    static const int g_lds[5] = {25, 45, 65, 100, 180}, g_l2[5] = {45, 120, 170, 230, 330};   // (LDS: 64 rays 24 us sorted straight through, 18 with the bulk zipped: e14)
+    // (the solo loop's cadence with treelets of 4 levels, round 6: 2.0 / 3.8 us per bounce -- 25 / 45 with 2 levels; irreg 700 x 700 -7 %, rgbbox 500 x 500 -7 %,
+    // 700 x 700 -4 %, the other sizes +-1 %: profiles/r06/exp/e7_solo_cadence_ab.txt.  LDS: 64 rays 24 us sorted straight through, 18 with the bulk zipped: r05 e14)
+    static const int g_lds[5] = {20, 45, 65, 100, 180}, g_l2[5] = {38, 120, 170, 230, 330};
     for (int k = 0; k < 5; ++k) pol.g[k] = ctx->px_g[k] > 0 ? ctx->px_g[k] : (whole_scene ? g_lds[k] : g_l2[k]);
     pol.ray_ns = ctx->px_ray_ns > 0 ? ctx->px_ray_ns : 250;
     pol.nwaves = pl.grid_full * pl.waves;
