@@ -692,7 +692,12 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // 0.43 unordered, from run to run; an OLDER sorted view predicts worse than no order at all (0.54).  (sync_policy = 1: the most recent
       // view whatever its state, behind a stream wait -- the same launches in every run, for tests and measurements; eager_sort = 0: the
       // pending sorts run in line, which waits for nothing either.)
-      if (!use && ctx->borrow && nframes == 1 && ctx->adaptive_order == 1) {
+      // (borrow = 1, auto: scenes read from L2 only.  A scene that lives in LDS has nothing pixel-stable to borrow -- rgbbox's long chains are chaotic
+      // pixel by pixel -- and its unordered frame, whose tail the DONATE waves walk in 4-level treelets, is now as fast as one through a neighbour's
+      // TILE order: rgbbox 1000 x 1000 0.462 ms unordered against 0.483 borrowed, 500 x 500 0.272 / 0.276; irreg 0.431 / 0.355, 0.273 / 0.229 --
+      // profiles/r06/cold_probe_*.txt.  borrow = 2 / 3 force the tile order / the list for either kind.)
+      const bool scene_in_lds = pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph;
+      if (!use && ctx->borrow && !(ctx->borrow == 1 && scene_in_lds) && nframes == 1 && ctx->adaptive_order == 1) {
         TileOrder *from = nullptr;
         for (auto &o : ps->orders) {
           if (&o == to || !same_shape(o) || !(o.valid || o.sort_pending)) continue;
@@ -746,14 +751,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     }
     // Pixel tickets (the ORD instantiation): an ordered single frame of a view that has its pixel list draws from it -- every
     // workgroup is launched (the longest chains ride in waves of their own from t = 0: the work bounds the frame, not they).
-    // (a BORROWED order, `borrow` = 1: through the other view's pixel list, holds and all, when the scene is read from L2; through its TILE order
-    // when the scene lives in LDS.  Camera path view by view, mean of the views behind the first, none / tiles / list / list without holds,
-    // profiles/r06/exp/e4_borrow_modes_*.txt: irreg 500 x 500 0.315 / 0.308 / 0.267 / 0.271 ms, 1000 x 1000 0.506 / 0.453 / 0.376 / 0.402,
-    // 1400 x 1400 0.620 / 0.556 / 0.498 / 0.516; rgbbox 0.335 / 0.313 / 0.343 / 0.347, 0.561 / 0.508 / 0.551 / 0.553, 0.785 / 0.734 / 0.791 / 0.803:
-    // irreg's long chains sit at the same pixels in neighbouring views -- grazing rays over the floor --, rgbbox's are chaotic pixel by pixel and
-    // stable only tile by tile.)
-    const bool whole_in_lds = pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph;
-    const bool borrow_tiles_only = borrowed && (ctx->borrow == 2 || (ctx->borrow == 1 && whole_in_lds));
+    // (a BORROWED order goes through the other view's pixel list, holds and all; borrow = 2: through its TILE order.  Camera path view by view, mean of
+    // the views behind the first, none / tiles / list / list without holds, with 2-level treelets, profiles/r06/exp/e4_borrow_modes_*.txt: irreg 500 x 500
+    // 0.315 / 0.308 / 0.267 / 0.271 ms, 1000 x 1000 0.506 / 0.453 / 0.376 / 0.402, 1400 x 1400 0.620 / 0.556 / 0.498 / 0.516; rgbbox 0.335 / 0.313 / 0.343 / 0.347,
+    // 0.561 / 0.508 / 0.551 / 0.553, 0.785 / 0.734 / 0.791 / 0.803.)
+    const bool borrow_tiles_only = borrowed && ctx->borrow == 2;
     if (use && use->valid && use->px_valid && nframes == 1 && pl.waves == 16 && ctx->adaptive_order == 1 && !borrow_tiles_only &&
         (p.nshards == 1 || p.interleave) && use->px_elems >= static_cast<size_t>(p.rows_local) * p.w && px_static_ok) {
       p.px_list = use->px_list;
