@@ -791,7 +791,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.deep_class = 0;
       first_order = true;
     }
-    // Culling by the best hit so far (the CULL instantiations; lane_core.h: cull_limit, DESIGN.md 3.5): where the scene's and the
+    // Culling by the best hit so far (the CULL instantiations; lane_core.h: cull_limit, DESIGN.md 3.4): where the scene's and the
     // camera's guards pass.  Auto leaves wholly LDS-resident scenes alone: their walks are short and LDS-fast, and the limit's three
     // instructions per item cost more than the tests it saves (rgbbox 1000 x 1000: -3 % box tests; tools/cull_pooled.cpp).
     if (cull_allowed(ctx, ps, pl, p, cams_dev, nframes)) {

@@ -370,7 +370,7 @@ int64_t part_rows(int64_t h, int32_t rows_per_tile, int32_t part, int32_t nparts
   return rows;
 }
 
-// ---- culling constants (rt_host.hpp; the derivation is DESIGN.md 3.5) ----
+// ---- culling constants (rt_host.hpp; the derivation is DESIGN.md 3.4) ----
 CullConst cull_scene_constants(const std::vector<Sphere> &ts, int height) {
   CullConst c;
   const size_t n = ts.size();

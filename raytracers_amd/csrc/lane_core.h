@@ -110,12 +110,12 @@ RT_HD bool box_hit(const Ray &r, float lox, float loy, float loz, float hix, flo
   return box_hit_clamped(r, lox, loy, loz, hix, hiy, hiz, kTMax);
 }
 
-// ---- culling by the best hit so far (the CULL instantiations of the pooled kernel; DESIGN.md 3.5) -------------------------
+// ---- culling by the best hit so far (the CULL instantiations of the pooled kernel; DESIGN.md 3.4) -------------------------
 // The reference's fold tests every leaf whose ancestors' boxes pass with the FIXED interval (0, 1e9) (ray.fut:77) -- it never
 // narrows the interval.  Only its RESULT is the contract: the smallest accepted root, ties to the lowest leaf.  A subtree may
 // therefore be skipped when every root any of its spheres could produce is proven LARGER than a root already found.
 //
-// The bound (proof and constants: DESIGN.md 3.5; tools/cull_bound_check.cpp hammers the two inequalities it rests on).  For a
+// The bound (proof and constants: DESIGN.md 3.4; tools/cull_bound_check.cpp hammers the two inequalities it rests on).  For a
 // ray (o, d) and a sphere (p, r) let g be ANY root sphere_root computes in binary32, P = o + g d the exact point at that
 // parameter, D = |o - p|, a = d.d.  Then
 //     | |P - p|^2 - r^2 |  <=  2^-18 (D^2 + r^2)                                                     (E1)

@@ -579,7 +579,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // COLD: the instantiation for SMALL single frames (~360 x 360 .. 800 x 800 pixels), whose time is what their last bounce chains
 // take.  A wave that cannot refill any more (the queue is dry, or it holds a deep tile) and is left with at most p.cold live
 // rays, all at a bounce boundary, hands them to solo_trace one after the other from INSIDE the loop.  The call costs this
-// instantiation 4-7 % in every regime (DESIGN.md 3.1.1) -- which is why the kernels of larger frames and batches do not have
+// instantiation 4-7 % in every regime (DESIGN.md 3.2) -- which is why the kernels of larger frames and batches do not have
 // it -- and a small frame gets it back: rgbbox 500 x 500, first frame 0.395 -> 0.333 ms (one ray), later frames 0.280 -> 0.225
 // (three); at 1000 x 1000 it is neutral to +2 % (profiles/r04/exp/e7, e8).  (TAIL == 1)
 // DONATE (TAIL == 2): the instantiation for UNORDERED single frames (a view's first).  Their long chains start whenever the raster
@@ -596,7 +596,7 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // per ticket.  A tile's 64 pixels mix one or two long chains with dozens of short ones, so a wave that holds a deep TILE parks most of
 // its slots, and one that does not walks the long chain at a full wave's cadence; a ticket of pixels with EQUAL chain lengths keeps
 // its wave exactly as full as the chain's deadline allows, and the last tickets of the queue are all one-ray pixels (no drain).
-// CULL: boxes are tested against the slot's best root so far instead of the fixed 1e9 (lane_core.h: cull_limit; DESIGN.md 3.5) -- a
+// CULL: boxes are tested against the slot's best root so far instead of the fixed 1e9 (lane_core.h: cull_limit; DESIGN.md 3.4) -- a
 // subtree whose every root is proven larger than a root already found is not walked.  Same pixels (the fold's RESULT is the contract,
 // ray.fut:76-86), fewer tests: irreg 1000 x 1000 -15 % box tests, -36 % sphere tests in this kernel's order (tools/cull_pooled.cpp).
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false>

@@ -89,7 +89,7 @@ struct TravLayout {
 };
 TravLayout make_trav_layout(const Lbvh &b, int treelet_depth = 1);
 
-// ---- culling by the best hit so far (lane_core.h: cull_limit; DESIGN.md 3.5) ----
+// ---- culling by the best hit so far (lane_core.h: cull_limit; DESIGN.md 3.4) ----
 // The scene's side of the proof: whether its rays may be culled at all, and the two constants of the limit
 // best + W2 (best^2 + kappa), W2 = max|1 / d_k| * (d.d) * c2.  `ok` needs
 //   * every box to contain the boxes of the spheres below it: tree height <= the reference's floor(log2 n) + 2 sweeps

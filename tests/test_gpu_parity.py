@@ -237,7 +237,7 @@ def test_solo_pixels_and_treelet_numbering(R, opts, gpu_build):
                                   dict(pixel_order=2, px_g1=1000, px_g64=20000, px_ray_ns=20000, thr_shade=8),
                                   dict(pixel_order=2, gpu_build=0, treelet=2), dict(pixel_order=2, xcd_queues=1)])
 def test_pixel_tickets(R, opts):
-    """Ordered single frames that draw their tickets from the view's PIXEL LIST (DESIGN.md 3.1.3: the first frame records every pixel's
+    """Ordered single frames that draw their tickets from the view's PIXEL LIST (DESIGN.md 3.3: the first frame records every pixel's
     chain length, the sorts run ahead of the second frame, the ORD instantiation renders from it): the list's classes cut by the device's
     model, by hand at both extremes, with and without holding / the solo loop / static first tickets, on one counter, with strips (no list:
     the tile tickets), by the host builder with another treelet cut (no solo loop).  Frames 1 .. 4 of a view into a poisoned buffer, a part
@@ -315,7 +315,7 @@ def test_pixel_tickets(R, opts):
                                   dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8), dict(cull=1, solo=0), dict(cull=1, lds_scene_bytes=0),
                                   dict(cull=1, gpu_build=0), dict(cull=1, look_max=1, thr_shade=64)])
 def test_cull_by_best_hit(R, opts):
-    """The CULL instantiations of the pooled kernel (DESIGN.md 3.5; lane_core.h: cull_limit): boxes are tested against the slot's best
+    """The CULL instantiations of the pooled kernel (DESIGN.md 3.4; lane_core.h: cull_limit): boxes are tested against the slot's best
     root so far, widened by a proven margin, instead of the reference's fixed 1e9 (ray.fut:77) -- fewer tests, the SAME fold result
     (ray.fut:76-86).  Every flavour (plain, SOLO, COLD, DONATE, ORD; BOX, BOX2 and the solo loop's treelet operation), frames 1 .. 4 of a
     view, a part packed and in place, batches with and without their own cameras; scenes: the reference's, floors, random spheres with

@@ -149,7 +149,7 @@ def test_treelet_numbering_and_masks_on_the_cpu(scene, size):
 
 
 def test_cull_limit_is_conservative_on_the_cpu():
-    """tools/cull_bound_check hammers the two inequalities the CULL instantiations rest on (lane_core.h: cull_limit; DESIGN.md 3.5)
+    """tools/cull_bound_check hammers the two inequalities the CULL instantiations rest on (lane_core.h: cull_limit; DESIGN.md 3.4)
     with the product's own binary32 code against __float128: (E1) a computed root lies within 2^-18 (D^2 + r^2) of the sphere,
     (S) a sphere's own box is never culled by the limit computed from that sphere's own root -- random and adversarial pairs
     (grazing, far, nearly axis-parallel, origin inside the sphere).  With the margin scaled down 1000 x the checker must FIND

@@ -5,7 +5,7 @@ whose chain needs more than d rays is black at d (ray_colour returns light * 0 w
 the smallest d at which it has its final colour bounds its chain.  Then: (a) how well do 1 / 4 / 8 sample pixels of an 8 x 8
 tile predict the tile's longest chain, (b) the scout: a frame of 1 / div^2 of the pixels with max_depth `cut`, a tile flagged
 when a scout pixel of its footprint is black -- how many tiles are flagged, and which fraction of the tiles with chains of
->= 8 / 16 / 32 are among them.      usage: chain_cluster_probe.py [size=1000]   """
+>= 8 / 16 / 32 are among them.      usage: chain_cluster_probe.py [size=1000]   (profiles/r04/README.md)"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 // cull_bound_check.cpp -- CPU check of the inequalities the CULL instantiations rest on (lane_core.h: cull_limit;
-// DESIGN.md 3.5).  Not a product path, not the oracle: a hammer for a proof.  In the CPU test suite (a short run).
+// DESIGN.md 3.4).  Not a product path, not the oracle: a hammer for a proof.  In the CPU test suite (a short run).
 //
 // For random and adversarial (ray, sphere) pairs inside the guards of rt::cull_scene_constants it checks, with the product's own
 // binary32 code for the roots, the box entry parameter and the limit, and __float128 for the truth:

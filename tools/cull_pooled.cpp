@@ -63,7 +63,7 @@ struct Counters {
   size_t max_box = 0;
 };
 struct Knobs { float m_abs = 0, m_rel = 0; int mode = 0, near_first = 0, thr_shade = 40, look_max = 32; float c2 = 0, kappa = 0, a_lo = 1.0f / 64; int rule = 0; };
-// the product's limit (DESIGN.md 3.5): best + W2 (best^2 + kappa), W2 = max|1/d_k| a c2 per ray (inf when a < a_lo)
+// the product's limit (DESIGN.md 3.4): best + W2 (best^2 + kappa), W2 = max|1/d_k| a c2 per ray (inf when a < a_lo)
 static inline float lim_rule(const Knobs &K, const Ray &r, float best) {
   const float M = fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz));
   const float W2 = r.a >= K.a_lo ? M * r.a * K.c2 : INFINITY;
