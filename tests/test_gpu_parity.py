@@ -311,9 +311,8 @@ def test_pixel_tickets(R, opts):
     c.close()
 
 
-@pytest.mark.parametrize("opts", [dict(cull=1), dict(cull=-1), dict(cull=0), dict(cull=1, pixel_order=2), dict(cull=1, pixel_order=0), dict(cull=1, pixel_order=0, deep_class=8, deep_split=6, deep_cap_log2=0),
-                                  dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8), dict(cull=1, solo=0), dict(cull=1, lds_scene_bytes=0),
-                                  dict(cull=1, gpu_build=0), dict(cull=1, look_max=1, thr_shade=64)])
+@pytest.mark.parametrize("opts", [dict(cull=1), dict(cull=-1), dict(cull=0), dict(cull=1, pixel_order=2, look_max=1, thr_shade=64), dict(cull=1, pixel_order=0, deep_class=8, deep_split=6, deep_cap_log2=0),
+                                  dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8, solo=0), dict(cull=1, lds_scene_bytes=0, gpu_build=0)])
 def test_cull_by_best_hit(R, opts):
     """The CULL instantiations of the pooled kernel (lane_core.h: cull_limit): boxes are tested against the slot's best
     root so far, widened by a proven margin, instead of the reference's fixed 1e9 (ray.fut:77) -- fewer tests, the SAME fold result
@@ -633,8 +632,8 @@ def test_camera_path_one_frame_at_a_time(R, scene, h, w):
     c.close(); plain.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(borrow=3), dict(borrow=2), dict(borrow=4, cull=1), dict(sync_policy=0), dict(eager_sort=0), dict(borrow=0), dict(borrow=0, eager_sort=0), dict(pixel_order=0), dict(pixel_order=2, handover=2, donate_max=8),
-                                  dict(handover=0), dict(cull=1), dict(solo=0, thr_shade=8), dict(gpu_build=0, treelet=2), dict(xcd_queues=0, static_first=0), dict(adaptive_order=2)])
+@pytest.mark.parametrize("opts", [dict(), dict(borrow=3), dict(borrow=2, cull=1), dict(borrow=4, handover=0), dict(sync_policy=0), dict(eager_sort=0), dict(borrow=0, eager_sort=0), dict(borrow=3, pixel_order=0),
+                                  dict(borrow=3, pixel_order=2, handover=2, donate_max=8), dict(borrow=3, solo=0, thr_shade=8), dict(borrow=3, gpu_build=0, treelet=2, xcd_queues=0, static_first=0), dict(adaptive_order=2)])
 def test_new_views_borrow_the_previous_views_order(R, opts):
     """Round 6: a NEW view of a prepared scene (another camera, same image size / partition) renders its first frame through the order /
     pixel list of the view rendered last (`borrow`), with the DONATE tail for the chains that list places wrongly (the ORD + DONATE
