@@ -27,6 +27,9 @@ namespace {
 
 constexpr int kBT = 256;          // threads per block everywhere in this file
 constexpr int kSortE = 4;         // sort: elements per thread (tile = 1024 per block)
+constexpr int kSortTile = kBT * kSortE;
+constexpr int kSortBits = 4, kSortDigits = 1 << kSortBits, kSortWords = kSortDigits / 4;   // sort: bits per pass
+constexpr int kRankMaxN = 24576;  // the RANKED sizes (sorts by ranking, one launch each): up to this many spheres
 
 __device__ __forceinline__ float f_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float f_max(float a, float b) { return fmaxf(a, b); }
@@ -43,9 +46,13 @@ __device__ __forceinline__ void sphere_centre(const float *s, float c[3]) {
   }
 }
 
-__global__ __launch_bounds__(kBT) void centres_minmax_kernel(const float *sph7, int n, float *centres, float *partial) {
+// (also zeroes the nzero counters of the chained sort passes, see sort_scatter_kernel)
+__global__ __launch_bounds__(kBT) void centres_minmax_kernel(const float *sph7, int n, float *centres, float *partial, unsigned *zero,
+                                                             int nzero, int *flags) {
   __shared__ float red[6][kBT];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBT + threadIdx.x; i < nzero; i += gridDim.x * kBT) zero[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < 4) flags[threadIdx.x] = 0;      // (the depth walk's maximum)
   for (int i = blockIdx.x * kBT + threadIdx.x; i < n; i += gridDim.x * kBT) {
     float c[3];
     sphere_centre(sph7 + 7 * (size_t)i, c);
@@ -75,15 +82,8 @@ __global__ __launch_bounds__(kBT) void centres_minmax_kernel(const float *sph7, 
   if (threadIdx.x < 6) partial[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(kBT) void minmax_final_kernel(const float *partial, int nblocks, float *bounds) {
-  __shared__ float red[6][kBT];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int b = threadIdx.x; b < nblocks; b += kBT)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      lo[a] = f_min(lo[a], partial[b * 6 + a]);
-      hi[a] = f_max(hi[a], partial[b * 6 + 3 + a]);
-    }
+// the threads' bounds -> red[0..5][0] (min.xyz, max.xyz); ends with a barrier
+__device__ __forceinline__ void block_reduce_bounds(const float lo[3], const float hi[3], float (*red)[kBT]) {
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     red[a][threadIdx.x] = lo[a];
@@ -100,6 +100,21 @@ __global__ __launch_bounds__(kBT) void minmax_final_kernel(const float *partial,
     }
     __syncthreads();
   }
+}
+// the blocks' partial bounds -> red[0..5][0], by one block
+__device__ __forceinline__ void reduce_partial_bounds(const float *partial, int nblocks, float (*red)[kBT]) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int b = threadIdx.x; b < nblocks; b += kBT)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = f_min(lo[a], partial[b * 6 + a]);
+      hi[a] = f_max(hi[a], partial[b * 6 + 3 + a]);
+    }
+  block_reduce_bounds(lo, hi, red);
+}
+__global__ __launch_bounds__(kBT) void minmax_final_kernel(const float *partial, int nblocks, float *bounds) {
+  __shared__ float red[6][kBT];
+  reduce_partial_bounds(partial, nblocks, red);
   if (threadIdx.x < 6) bounds[threadIdx.x] = red[threadIdx.x][0];   // min.xyz, max.xyz
 }
 
@@ -113,21 +128,75 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
 }
 __device__ __forceinline__ unsigned quantise10(float q) { return (unsigned)f_min(f_max(q * 1024.0f, 0.0f), 1023.0f); }
 
-__device__ __forceinline__ void morton_elem(int i, const float *centres, const float *bounds, unsigned *keys, int *vals) {
+__device__ __forceinline__ unsigned morton_code(float cx, float cy, float cz, const float *bounds) {
+  const float c[3] = {cx, cy, cz};
   unsigned code[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float mn = bounds[a], mx = bounds[3 + a];
-    const float q = (centres[3 * (size_t)i + a] - mn) / (mx - mn);   // 0/0 = NaN on a flat axis -> 0 below
+    const float q = (c[a] - mn) / (mx - mn);   // 0/0 = NaN on a flat axis -> 0 below
     code[a] = spread10(quantise10(q));
   }
-  keys[i] = code[0] * 4u + code[1] * 2u + code[2];
+  return code[0] * 4u + code[1] * 2u + code[2];
+}
+__device__ __forceinline__ void morton_elem(int i, const float *centres, const float *bounds, unsigned *keys, int *vals) {
+  keys[i] = morton_code(centres[3 * (size_t)i], centres[3 * (size_t)i + 1], centres[3 * (size_t)i + 2], bounds);
   vals[i] = i;
 }
 __global__ __launch_bounds__(kBT) void morton_kernel(const float *centres, const float *bounds, int n, unsigned *keys,
                                                      int *vals) {
   const int i = blockIdx.x * kBT + threadIdx.x;
   if (i < n) morton_elem(i, centres, bounds, keys, vals);
+}
+// CHAINED flavour for scenes whose sort runs without count launches (sort_scatter_kernel): every block reduces the partial bounds
+// itself (the same reduction tree as minmax_final_kernel: the same six floats) and leaves the first pass's digit counts of its
+// 256 keys -- a quarter of a sort tile -- in block_counts.
+__device__ __forceinline__ void chain_count_block(unsigned digit, bool live, unsigned *block_counts, int nblocks, unsigned *hist) {
+  if (threadIdx.x < kSortDigits) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  if (live) atomicAdd(&hist[digit], 1u);
+  __syncthreads();
+  if (threadIdx.x < kSortDigits && hist[threadIdx.x])
+    atomicAdd(&block_counts[threadIdx.x * nblocks + (int)(blockIdx.x / (kSortTile / kBT))], hist[threadIdx.x]);
+}
+__global__ __launch_bounds__(kBT) void morton_chain_kernel(const float *centres, const float *partial, int red_blocks, int n,
+                                                           unsigned *keys, int *vals, unsigned *block_counts, int nblocks) {
+  __shared__ float red[6][kBT];
+  __shared__ float s_bounds[6];
+  __shared__ unsigned hist[kSortDigits];
+  reduce_partial_bounds(partial, red_blocks, red);
+  if (threadIdx.x < 6) s_bounds[threadIdx.x] = red[threadIdx.x][0];
+  __syncthreads();
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i < n) morton_elem(i, centres, s_bounds, keys, vals);
+  chain_count_block(i < n ? keys[i] & (unsigned)(kSortDigits - 1) : 0u, i < n, block_counts, nblocks, hist);
+}
+
+// The RANKED sizes' first launch: every block takes the bounds of ALL centres itself (n <= kRankMaxN spheres: 4 floats of each, from L2) and
+// writes its 256 keys -- no centres array, no launch for the bounds.  (fmin / fmax: the same six floats in whatever order they are folded.)
+__global__ __launch_bounds__(kBT) void morton_all_kernel(const float *__restrict__ sph7, int n, unsigned *keys, int *flags) {
+  __shared__ float red[6][kBT];
+  __shared__ float s_bounds[6];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 8
+  for (int j = threadIdx.x; j < n; j += kBT) {
+    float c[3];
+    sphere_centre(sph7 + 7 * (size_t)j, c);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = f_min(lo[a], c[a]);
+      hi[a] = f_max(hi[a], c[a]);
+    }
+  }
+  block_reduce_bounds(lo, hi, red);
+  if (threadIdx.x < 6) s_bounds[threadIdx.x] = red[threadIdx.x][0];
+  if (blockIdx.x == 0 && threadIdx.x < 4) flags[threadIdx.x] = 0;      // (the depth walk's maximum)
+  __syncthreads();
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i >= n) return;
+  float c[3];
+  sphere_centre(sph7 + 7 * (size_t)i, c);
+  keys[i] = morton_code(c[0], c[1], c[2], s_bounds);
 }
 
 // ---- stable LSD radix sort of (key, val), 4 bits per pass ---------------------------------
@@ -158,7 +227,6 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 }
 
 // digit counts of kSortE elements, 16 bits per digit value, four values per u64 word
-constexpr int kSortBits = 4, kSortDigits = 1 << kSortBits, kSortWords = kSortDigits / 4;
 struct DigitCounts {
   unsigned long long w[kSortWords];
 };
@@ -218,12 +286,20 @@ __global__ __launch_bounds__(kBT) void scan_small_kernel(unsigned *data, int m) 
 // derives its own 16 offsets from them -- digit-major exclusive prefix: the elements of smaller digits in all blocks, then
 // those of the same digit in the blocks before this one.  For scenes of up to kSortRawBlocks blocks (131 072 elements), where
 // a dispatch (~3.5 us of dependent-launch gap) costs more than 16 x nblocks loads per block.
+// CHAIN (with RAW): the pass also leaves the NEXT pass's block counts (next_counts, zero before the launch; next_shift its digit):
+// the elements of one digit land in consecutive places, at most kSortTile of them, so in at most two tiles of the output; the
+// block counts {tile half, digit, next digit} in LDS and adds what is not zero to the output tiles' counters.  Integer adds: any
+// order, the same counts.  A chained sort is one launch per pass, its first counts come from the kernel that writes the keys.
 constexpr int kSortRawBlocks = 128;
-template <bool RAW>
+template <bool RAW, bool CHAIN = false>
 __global__ __launch_bounds__(kBT) void sort_scatter_kernel(const unsigned *keys_in, const int *vals_in, int n, int shift,
                                                            const unsigned *block_offsets, int nblocks, unsigned *keys_out,
-                                                           int *vals_out) {
+                                                           int *vals_out, unsigned *next_counts = nullptr, int next_shift = 0) {
+  static_assert(RAW || !CHAIN, "a chained pass derives its offsets from the raw counts");
   __shared__ unsigned s_all[kSortDigits][kBT / kSortDigits], s_before[kSortDigits][kBT / kSortDigits], s_off[kSortDigits];
+  __shared__ unsigned s_next[CHAIN ? 2 * kSortDigits * kSortDigits : 1];
+  if (CHAIN)
+    for (int j = threadIdx.x; j < 2 * kSortDigits * kSortDigits; j += kBT) s_next[j] = 0u;
   if (RAW) {
     const int d = threadIdx.x & (kSortDigits - 1), c = threadIdx.x / kSortDigits;   // digit, chunk of the block list
     unsigned all = 0, before = 0;
@@ -269,18 +345,36 @@ __global__ __launch_bounds__(kBT) void sort_scatter_kernel(const unsigned *keys_
       keys_out[pos] = k[e];
       vals_out[pos] = v[e];
       digit_add(rank, d);
+      if (CHAIN && next_counts) {
+        const unsigned half = pos / kSortTile - s_off[d] / kSortTile, dn = (k[e] >> next_shift) & (kSortDigits - 1);
+        atomicAdd(&s_next[(half * kSortDigits + d) * kSortDigits + dn], 1u);
+      }
+    }
+  }
+  if (CHAIN && next_counts) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * kSortDigits * kSortDigits; j += kBT) {
+      const unsigned c = s_next[j];
+      if (c) {
+        const unsigned half = j / (kSortDigits * kSortDigits), d = (j / kSortDigits) % kSortDigits, dn = j % kSortDigits;
+        atomicAdd(&next_counts[dn * nblocks + s_off[d] / kSortTile + half], c);
+      }
     }
   }
 }
 
 // ---- gather sorted spheres ----------------------------------------------------------------
-__global__ __launch_bounds__(kBT) void gather_spheres_kernel(const float *sph7, const int *order, int n, float *L7) {
+// (... and the traversal copy's sphere tables {pos, radius} {colour, 1 / radius} in the same launch: they are a function of L alone)
+__global__ __launch_bounds__(kBT) void gather_spheres_kernel(const float *sph7, const int *order, int n, float *L7, float4 *sph, float4 *col) {
   const int i = blockIdx.x * kBT + threadIdx.x;
   if (i >= n) return;
   const float *s = sph7 + 7 * (size_t)order[i];
   float *d = L7 + 7 * (size_t)i;
+  float v[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) d[k] = s[k];
+  for (int k = 0; k < 7; ++k) { v[k] = s[k]; d[k] = v[k]; }
+  sph[i] = make_float4(v[0], v[1], v[2], v[6]);
+  col[i] = make_float4(v[3], v[4], v[5], 1.0f / v[6]);
 }
 
 // ---- radix tree (radixtree.fut:13-72) -----------------------------------------------------
@@ -335,6 +429,45 @@ __global__ __launch_bounds__(kBT) void build_fills_kernel(int *parent, float *pm
   }
 }
 
+// The sorted spheres AND the radix tree in one launch (the fused-sweep sizes): thread i gathers sphere i and builds inner node i.  Nothing is
+// filled ahead of it: every inner node but the root is some node's child and gets its parent link from it, the root is node 0.
+// LDSKEYS (the ranked sizes): all sorted keys staged in LDS first -- a node's ~2 log2(n) dependent key reads cost LDS latency, not L2's.
+template <bool LDSKEYS>
+__global__ __launch_bounds__(kBT) void tree_kernel(const unsigned *__restrict__ L, const int *__restrict__ order, const float *__restrict__ sph7,
+                                                   int n, float *__restrict__ L7, float4 *__restrict__ sph, float4 *__restrict__ col,
+                                                   int *left, int *right, int *parent) {
+  extern __shared__ unsigned s_L[];
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  float v[7];
+  if (i < n) {
+    const float *src = sph7 + 7 * (size_t)order[i];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = src[k];
+  }
+  if (LDSKEYS) {
+    constexpr int kPer = kRankMaxN / kBT;
+    unsigned w[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int j = (int)threadIdx.x + u * kBT;
+      if (j < n) w[u] = L[j];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int j = (int)threadIdx.x + u * kBT;
+      if (j < n) s_L[j] = w[u];
+    }
+    __syncthreads();
+  }
+  if (i >= n) return;
+  float *d = L7 + 7 * (size_t)i;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) d[k] = v[k];
+  sph[i] = make_float4(v[0], v[1], v[2], v[6]);
+  col[i] = make_float4(v[3], v[4], v[5], 1.0f / v[6]);
+  if (i == 0) parent[0] = -1;
+  if (i < n - 1) radix_tree_node(i, LDSKEYS ? s_L : L, n, left, right, parent);
+}
 __global__ __launch_bounds__(kBT) void radix_tree_kernel(const unsigned *L, int n, int *left, int *right, int *parent) {
   const int i = blockIdx.x * kBT + threadIdx.x;
   if (i < n - 1) radix_tree_node(i, L, n, left, right, parent);
@@ -388,10 +521,67 @@ __global__ __launch_bounds__(kBT) void aabb_sweep_kernel(const float *L7, const 
   }
 }
 
+// Several Jacobi sweeps in ONE launch (mid-size scenes, where the build is a chain of ~4.4 us dispatches and 15-19 of them are sweeps):
+// box_{s+K}(i) is a pure function of the boxes K sweeps earlier at most K levels below i -- enclosing(box_{s+K-1}(left), box_{s+K-1}(right)), each of
+// those the same one level down, a leaf child contributing its sphere's box at every level -- and enclosing is componentwise fmin / fmax: no rounding,
+// so composing K levels in one thread gives the very bits K launches would.  Reads the buffer of sweep s only (complete: written by an earlier launch),
+// writes sweep s + K for every node.
+struct Box3 { float lo[3], hi[3]; };
+// (FIRST: the launch that starts the sweeps -- "the boxes of sweep 0" are all zero, nothing is read and nothing had to be filled)
+template <int K, bool FIRST>
+__device__ __forceinline__ Box3 box_after(int ptr, const float *L7, const int *left, const int *right, const float *pmin, const float *pmax) {
+  Box3 b;
+  if (ptr <= -2) {                      // a leaf: sphere_aabb (ray.fut:28-30), whatever the sweep
+    const float *s = L7 + 7 * (size_t)(-2 - ptr);
+    const float r = s[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { b.lo[a] = s[a] - r; b.hi[a] = s[a] + r; }
+    return b;
+  }
+  if constexpr (K == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      b.lo[a] = FIRST ? 0.0f : pmin[3 * (size_t)ptr + a];
+      b.hi[a] = FIRST ? 0.0f : pmax[3 * (size_t)ptr + a];
+    }
+    return b;
+  } else {
+    const Box3 l = box_after<K - 1, FIRST>(left[ptr], L7, left, right, pmin, pmax), r = box_after<K - 1, FIRST>(right[ptr], L7, left, right, pmin, pmax);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { b.lo[a] = f_min(l.lo[a], r.lo[a]); b.hi[a] = f_max(l.hi[a], r.hi[a]); }   // enclosing, prim.fut:38-45
+    return b;
+  }
+}
+// (... the FIRST launch also walks every node up to the root -- depth_walk_kernel's work, which needs the parent links and nothing of the sweeps)
+template <int K, bool FIRST>
+__global__ __launch_bounds__(kBT) void aabb_sweepk_kernel(const float *L7, const int *left, const int *right, int ni, const float *pmin, const float *pmax,
+                                                          float *cmin, float *cmax, const int *parent, unsigned *depth_keys, int *maxdepth) {
+  const int i = blockIdx.x * kBT + threadIdx.x;
+  if (i < ni) {
+    const Box3 b = box_after<K, FIRST>(i, L7, left, right, pmin, pmax);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cmin[3 * (size_t)i + a] = b.lo[a]; cmax[3 * (size_t)i + a] = b.hi[a]; }
+  }
+  if (FIRST && parent) {
+    int d = 0;
+    if (i < ni) {
+      for (int p = parent[i]; p >= 0; p = parent[p]) ++d;
+      depth_keys[i] = (unsigned)d;
+    }
+    for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxdepth, d);
+  }
+}
+constexpr int kSweepLevels = 3;        // sweeps per launch of the mid-size path (measured at 10^4 spheres: 3 levels 8.4 us a launch, 5 levels 24-29 us)
+constexpr int kSweepFusedMaxN = 131072;   // ... used up to this many spheres (beyond: one sweep per launch, with the nodes that are final dropping out)
+
 // ---- node depths (for the traversal numbering) ----------------------------------------------
 // depth of every inner node = number of ancestors (walk up the parent links), written as the
 // sort key of the traversal numbering; also the maximum depth
-__global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int ni, unsigned *keys, int *vals, int *maxdepth) {
+// (block_counts: the first digit counts of a chained sort, see morton_chain_kernel; nullptr = none)
+__global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int ni, unsigned *keys, int *vals, int *maxdepth,
+                                                         unsigned *block_counts, int nblocks) {
+  __shared__ unsigned hist[kSortDigits];
   const int i = blockIdx.x * kBT + threadIdx.x;
   int d = 0;
   if (i < ni) {
@@ -399,6 +589,7 @@ __global__ __launch_bounds__(kBT) void depth_walk_kernel(const int *parent, int 
     keys[i] = (unsigned)d;
     vals[i] = i;
   }
+  if (block_counts) chain_count_block((unsigned)d & (unsigned)(kSortDigits - 1), i < ni, block_counts, nblocks, hist);
   for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0) atomicMax(maxdepth, d);
 }
@@ -443,11 +634,14 @@ __device__ __forceinline__ int treelet_root(int c, int rel, const int *parent, c
   *heap = (1 << rel) - 1 + path;
   return a;
 }
+// (... and the inverse of the numbering by depth, trav_of[order[t]] = t, in the same launch)
 __global__ __launch_bounds__(kBT) void treelet_size_kernel(const unsigned *depth_sorted, const int *order, const int *left,
-                                                           const int *right, int ni, unsigned *size) {
+                                                           const int *right, int ni, unsigned *size, int *trav_of) {
   const int t = blockIdx.x * kBT + threadIdx.x;
   if (t >= ni) return;
-  size[t] = (depth_sorted[t] % (unsigned)kTreeletDepth) ? 0u : (unsigned)tl_popc(treelet_occ(order[t], left, right));
+  const int c = order[t];
+  trav_of[c] = t;
+  size[t] = (depth_sorted[t] % (unsigned)kTreeletDepth) ? 0u : (unsigned)tl_popc(treelet_occ(c, left, right));
 }
 constexpr int kScanE = 4;   // elements per thread of the multi-block scan
 __global__ __launch_bounds__(kBT) void scan_sums_kernel(const unsigned *v, int n, unsigned *sums) {
@@ -476,12 +670,16 @@ __global__ __launch_bounds__(kBT) void scan_apply_kernel(unsigned *v, int n, con
   }
 }
 // a node's new index (+ its heap index in its treelet, packed: treelet.h) from the treelet starts
-__device__ __forceinline__ unsigned treelet_place(int c, const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
-                                                 const int *parent, const int *left, const int *right) {
-  const int rel = (int)(depth_sorted[trav_by_depth[c]] % (unsigned)kTreeletDepth);
+// (rel: the node's depth inside its treelet, depth % kTreeletDepth)
+__device__ __forceinline__ unsigned treelet_place_rel(int c, int rel, const unsigned *start, const int *trav_by_depth, const int *parent,
+                                                     const int *left, const int *right) {
   int heap;
   const int r = treelet_root(c, rel, parent, right, &heap);
   return tl_pack_place(start[trav_by_depth[r]] + (unsigned)tl_pos(treelet_occ(r, left, right), heap), heap);
+}
+__device__ __forceinline__ unsigned treelet_place(int c, const unsigned *depth_sorted, const unsigned *start, const int *trav_by_depth,
+                                                 const int *parent, const int *left, const int *right) {
+  return treelet_place_rel(c, (int)(depth_sorted[trav_by_depth[c]] % (unsigned)kTreeletDepth), start, trav_by_depth, parent, left, right);
 }
 // the two mask dwords of canonical node c, whose packed place is `place` (treelet.h: tl_masks)
 __device__ __forceinline__ TlMasks treelet_masks(int c, unsigned place, const int *parent, const int *left, const int *right) {
@@ -500,9 +698,138 @@ __global__ __launch_bounds__(kBT) void treelet_number_kernel(const unsigned *dep
   order[pl & kTlIndexMask] = c;
 }
 
-__global__ __launch_bounds__(kBT) void invert_kernel(const int *order, int ni, int *trav_of) {
-  const int t = blockIdx.x * kBT + threadIdx.x;
-  if (t < ni) trav_of[order[t]] = t;
+
+// ---- mid-size scenes (kSmallUse < n <= kRankMaxN): sorts by ranking, scans by every block -------------------------------------
+// Here a launch is ~4.5 us of dependent-dispatch latency and a radix-sort pass ~8 us, whatever it does: the build is priced in
+// LAUNCHES.  A stable sort by key is the sort by (key, index), so an element's place is the number of elements whose (key, index)
+// is smaller, and that can be had in ONE launch: every block stages all n keys in LDS and buckets them by their leading bits
+// (a histogram, its scan, the members' indices listed bucket by bucket -- the same work in every block, ~10^4 LDS operations);
+// an element's place is then its bucket's start plus the number of smaller (key, index) among the bucket's members, counted by
+// 8 lanes per element, 64 elements per block.  The bucket is a monotone function of (key, index), so any distribution is sorted
+// right; one bucket holding everything (all keys equal) costs n / 8 compares per lane, ~10 us.  (All pairs against all tiles -- a v_cmp
+// and the population count of its mask per element and tile -- was tried first: the scalar unit waits ~25 cycles for every mask,
+// 34 us for 10^4 keys.)
+// DEPTH: the keys are node depths, vals the nodes (the numbering by depth); the lane that places node c also writes the inverse
+// numbering and, for a treelet root, its treelet's size (treelet_size_kernel).
+constexpr int kRankNT = 512, kRankBuckets = 2 * kRankNT, kRankLanes = 8, kRankPerBlock = kRankNT / kRankLanes;
+// the bucket of (key, index): monotone in that pair's order.  Morton keys: their leading 10 bits.  Depths (< 64, beyond: one last
+// bucket row): 16 slices of the index range per depth -- a level of the tree holds up to half the nodes.
+template <bool DEPTH>
+__device__ __forceinline__ unsigned rank_bucket(unsigned key, int j, int slice_shift) {
+  return DEPTH ? min(key, 63u) * 16u + ((unsigned)j >> slice_shift) : min(key >> 20, (unsigned)kRankBuckets - 1u);
+}
+inline size_t rank_sort_lds_bytes(int n) { return (sizeof(unsigned) + sizeof(unsigned short)) * 64 * (size_t)((n + 63) / 64); }
+template <bool DEPTH>
+__global__ __launch_bounds__(kRankNT) void rank_sort_kernel(const unsigned *__restrict__ keys_in, int n, unsigned *__restrict__ keys_out,
+                                                            int *__restrict__ vals_out, const int *__restrict__ left,
+                                                            const int *__restrict__ right, unsigned *__restrict__ size,
+                                                            int *__restrict__ trav_of) {
+  extern __shared__ unsigned s_keys[];          // n keys (padded to whole tiles of 64), then the bucket lists: n indices of 16 bits
+  __shared__ unsigned s_hist[kRankBuckets], s_off[kRankBuckets], s_wave[kRankNT / 64];
+  const int npad = 64 * ((n + 63) / 64);
+  const int slice_shift = max(0, 32 - __clz(n - 1) - 4);      // index >> slice_shift < 16
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_keys + npad);
+  constexpr int kPer = kRankMaxN / kRankNT;     // elements per thread of the bucketing phases: j = thread + u * kRankNT
+  {   // staging: all loads in flight before the first LDS write
+    unsigned v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int j = (int)threadIdx.x + u * kRankNT;
+      if (j < n) v[u] = keys_in[j];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int j = (int)threadIdx.x + u * kRankNT;
+      if (j < n) s_keys[j] = v[u];
+    }
+  }
+  s_hist[threadIdx.x] = 0u;
+  s_hist[threadIdx.x + kRankNT] = 0u;
+  __syncthreads();
+  unsigned pos[kPer];                           // the element's place among its bucket's members (any order: the count below looks at indices)
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int j = (int)threadIdx.x + u * kRankNT;
+    if (j < n) pos[u] = atomicAdd(&s_hist[rank_bucket<DEPTH>(s_keys[j], j, slice_shift)], 1u);
+  }
+  __syncthreads();
+  {                                             // exclusive scan of the histogram, two buckets per thread
+    const unsigned h0 = s_hist[2 * threadIdx.x], h1 = s_hist[2 * threadIdx.x + 1];
+    unsigned incl = h0 + h1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o);
+      if ((int)(threadIdx.x & 63) >= o) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned base = incl - h0 - h1;
+#pragma unroll
+    for (int w = 0; w < kRankNT / 64; ++w) base += w < (int)(threadIdx.x >> 6) ? s_wave[w] : 0u;
+    s_off[2 * threadIdx.x] = base;
+    s_off[2 * threadIdx.x + 1] = base + h0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int j = (int)threadIdx.x + u * kRankNT;
+    if (j < n) s_list[s_off[rank_bucket<DEPTH>(s_keys[j], j, slice_shift)] + pos[u]] = (unsigned short)j;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & (kRankLanes - 1), i = min((int)blockIdx.x * kRankPerBlock + (int)(threadIdx.x / kRankLanes), n - 1);
+  const unsigned ki = s_keys[i], bk = rank_bucket<DEPTH>(ki, i, slice_shift), beg = s_off[bk], end = beg + s_hist[bk];
+  unsigned cnt = 0;
+  for (unsigned m = beg + sub; m < end; m += kRankLanes) {
+    const int j = s_list[m];
+    const unsigned kj = s_keys[j];
+    cnt += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 1; o < kRankLanes; o <<= 1) cnt += __shfl_xor(cnt, o);
+  if (sub != 0 || (int)blockIdx.x * kRankPerBlock + (int)(threadIdx.x / kRankLanes) >= n) return;
+  const unsigned r = beg + cnt;
+  keys_out[r] = ki;
+  vals_out[r] = i;
+  if (DEPTH) {
+    trav_of[i] = (int)r;
+    size[r] = (ki % (unsigned)kTreeletDepth) ? 0u : (unsigned)tl_popc(treelet_occ(i, left, right));
+  }
+}
+// treelet_number_kernel whose every block scans the treelet sizes itself (into LDS) instead of three scan launches ahead of it
+constexpr int kNumNT = 1024;
+__global__ __launch_bounds__(kNumNT) void treelet_number_scan_kernel(const unsigned *depth_by_node, const unsigned *size, const int *trav_by_depth,
+                                                                     const int *parent, const int *left, const int *right, int ni, int *place,
+                                                                     int *order) {
+  extern __shared__ unsigned s_start[];     // exclusive scan of size[0 .. ni), padded to whole rounds of 4 * kNumNT
+  constexpr int kRounds = (kRankMaxN + 4 * kNumNT - 1) / (4 * kNumNT);
+  uint4 x[kRounds];
+#pragma unroll
+  for (int u = 0; u < kRounds; ++u) {       // (size[] is a scratch piece of >= 3 * ni floats: whole quads are readable)
+    const int i0 = (u * kNumNT + (int)threadIdx.x) * 4;
+    x[u] = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 < ni) {
+      x[u] = reinterpret_cast<const uint4 *>(size)[i0 / 4];
+      x[u].y = i0 + 1 < ni ? x[u].y : 0u;
+      x[u].z = i0 + 2 < ni ? x[u].z : 0u;
+      x[u].w = i0 + 3 < ni ? x[u].w : 0u;
+    }
+  }
+  unsigned carry = 0;
+#pragma unroll
+  for (int u = 0; u < kRounds; ++u) {
+    if (u * kNumNT * 4 >= ni) break;
+    unsigned long long tot;
+    const unsigned run = carry + (unsigned)block_excl_scan_u64<kNumNT>(x[u].x + x[u].y + x[u].z + x[u].w, &tot);
+    reinterpret_cast<uint4 *>(s_start)[u * kNumNT + (int)threadIdx.x] = make_uint4(run, run + x[u].x, run + x[u].x + x[u].y, run + x[u].x + x[u].y + x[u].z);
+    carry += (unsigned)tot;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * kNumNT + threadIdx.x;
+  if (c >= ni) return;
+  // (the depths by canonical node are still where the sweeps' first launch wrote them: one load instead of two dependent ones)
+  const unsigned pl = treelet_place_rel(c, (int)(depth_by_node[c] % (unsigned)kTreeletDepth), s_start, trav_by_depth, parent, left, right);
+  place[c] = (int)pl;
+  order[pl & kTlIndexMask] = c;
 }
 
 // ---- traversal copy ---------------------------------------------------------------------------
@@ -537,20 +864,21 @@ __device__ __forceinline__ void trav_node(int t, const int *order, const int *tr
   nodes32[2 * (size_t)t + 0] = make_float4(mn[0], mn[1], mn[2], __int_as_float(ref[0]));
   nodes32[2 * (size_t)t + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(ref[1]));
 }
+// (report: the host-pinned block of gpu_build_pinned_bytes() -- the thread of the root's record, t == 0, writes the maximum depth and that record
+// straight into it, which the two copies behind the launch used to do; nullptr = no report)
 __global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const int *trav_of, const int *parent, const int *left,
                                                          const int *right, const float *bmin, const float *bmax, int ni,
-                                                         float4 *nodes32, float4 *nodes64) {
+                                                         float4 *nodes32, float4 *nodes64, const int *maxdepth, int *report) {
   const int t = blockIdx.x * kBT + threadIdx.x;
-  if (t < ni) trav_node(t, order, trav_of, parent, left, right, bmin, bmax, nodes32, nodes64);
+  if (t >= ni) return;
+  trav_node(t, order, trav_of, parent, left, right, bmin, bmax, nodes32, nodes64);
+  if (t == 0 && report) {
+    report[0] = *maxdepth;
+    reinterpret_cast<float4 *>(report + 4)[0] = nodes32[0];
+    reinterpret_cast<float4 *>(report + 4)[1] = nodes32[1];
+  }
 }
 
-__global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int n, float4 *sph, float4 *col) {
-  const int i = blockIdx.x * kBT + threadIdx.x;
-  if (i >= n) return;
-  const float *s = L7 + 7 * (size_t)i;
-  sph[i] = make_float4(s[0], s[1], s[2], s[6]);
-  col[i] = make_float4(s[3], s[4], s[5], 1.0f / s[6]);
-}
 
 // ---- small scenes: the whole build in ONE workgroup, one launch ---------------------------------
 // For n <= kSmallMax everything above runs inside a single 1024-thread workgroup with
@@ -560,9 +888,18 @@ __global__ __launch_bounds__(kBT) void trav_spheres_kernel(const float *L7, int 
 // the traversal numbering live in LDS (2 x 4n bytes <= 128 KB); boxes stay in global memory (L2).
 constexpr int kSmallNT = 1024;
 constexpr int kSmallMax = 16384;   // digit totals fit the packed 16-bit counters
-// ... and it is USED up to kSmallUse spheres: one workgroup takes 0.089 ms + 28 ns per sphere beyond 1000, the chain of launches
-// below 0.25 ms + 0.7 ns per sphere (profiles/r03/exp/bvh_sizes_before.txt: 0.527 ms at n = 16 384 against 0.254 at 16 641)
-constexpr int kSmallUse = 6144;
+// ... and it is USED up to kSmallUse spheres: one workgroup takes 0.079 ms at 400 spheres, 0.093 at 1000, 0.125 at 2000, 0.26 at 6144; the ranked
+// chain of 11 launches 0.074-0.080 / 0.084 / 0.091 / 0.110 (profiles/r06/exp/e8_prepare_sizes.txt; until round 6 the chain was ~45 launches,
+// 0.25 ms, and the crossover 6144)
+constexpr int kSmallUse = 768;
+inline int small_use() {          // (RT_BVH_SMALL_USE: a measurement aid, the crossover between the one-workgroup build and the ranked chain)
+  static const int v = [] {
+    const char *e = getenv("RT_BVH_SMALL_USE");
+    const int x = e ? atoi(e) : kSmallUse;
+    return x < 2 ? 2 : (x > kSmallMax ? kSmallMax : x);
+  }();
+  return v;
+}
 constexpr int kSmallE = 17;        // consecutive elements a thread owns in a sort pass (odd: LDS stride)
 
 struct SmallArgs {
@@ -944,6 +1281,14 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
   }
   return hipGetLastError();
 }
+// ... and a chained one: the counts are there already, the pass leaves the next pass's (next == nullptr: the last pass)
+hipError_t sort_pass_chained(const unsigned *kin, const int *vin, unsigned *kout, int *vout, int n, int shift, const unsigned *counts,
+                             unsigned *next, hipStream_t st) {
+  const int nblocks = cdiv(n, kSortTile);
+  hipLaunchKernelGGL((sort_scatter_kernel<true, true>), dim3(nblocks), dim3(kBT), 0, st, kin, vin, n, shift, counts, nblocks, kout, vout,
+                     next, shift + kSortBits);
+  return hipGetLastError();
+}
 
 }  // namespace
 
@@ -954,9 +1299,10 @@ hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *v
   } while (0)
 
 namespace {
+constexpr int kKeyPasses = (30 + kSortBits - 1) / kSortBits, kDepthPasses = (6 + kSortBits - 1) / kSortBits, kChainPasses = kKeyPasses + kDepthPasses;
 // device scratch of one build, carved from one caller-provided block (256-byte aligned pieces)
 struct ScratchLayout {
-  size_t centres, partial, bounds, k0, k1, v0, v1, counts, bufmin, bufmax, depth, trav, flags, box4, total;
+  size_t centres, partial, bounds, k0, k1, v0, v1, counts, chain, bufmin, bufmax, depth, trav, flags, box4, total;
 };
 ScratchLayout scratch_layout(int n) {
   const size_t ni = (size_t)n - 1;
@@ -966,7 +1312,7 @@ ScratchLayout scratch_layout(int n) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
   l.centres = carve(sizeof(float) * 3 * (size_t)n);
-  if (n <= kSmallUse) {
+  if (n <= small_use()) {
     l.box4 = carve(sizeof(float4) * 4 * ni);
     l.v0 = carve(sizeof(int) * ni);
     l.trav = carve(sizeof(int) * ni);
@@ -978,6 +1324,7 @@ ScratchLayout scratch_layout(int n) {
     l.v0 = carve(sizeof(int) * (size_t)n);
     l.v1 = carve(sizeof(int) * (size_t)n);
     l.counts = carve(sizeof(unsigned) * kSortDigits * sort_blocks + 16);
+    l.chain = carve(sizeof(unsigned) * kSortDigits * (sort_blocks <= kSortRawBlocks ? sort_blocks : 0) * kChainPasses);
     l.bufmin = carve(sizeof(float) * 3 * ni);
     l.bufmax = carve(sizeof(float) * 3 * ni);
     l.depth = carve(sizeof(int) * ni);
@@ -990,9 +1337,15 @@ ScratchLayout scratch_layout(int n) {
 }  // namespace
 
 size_t gpu_build_scratch_bytes(int n) { return scratch_layout(n).total; }
-void warm_build_kernels() {   // see warm_render_kernels
+void warm_build_kernels() {   // see warm_render_kernels; with the context's device current
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, (const void *)bvh_small_kernel);
+  // (above 64 KB of LDS a kernel has to say so, per device; here and not between two launches of a build: the host is barely ahead of the device there)
+  (void)hipFuncSetAttribute((const void *)rank_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kRankMaxN));
+  (void)hipFuncSetAttribute((const void *)rank_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kRankMaxN));
+  (void)hipFuncSetAttribute((const void *)tree_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(unsigned) * kRankMaxN);
+  (void)hipFuncSetAttribute((const void *)treelet_number_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(unsigned) * 4 * kNumNT * ((kRankMaxN + 4 * kNumNT - 1) / (4 * kNumNT)));
 }
 // host-pinned block the kernels report through: [0] max depth, [1] "depth changed" flag,
 // [4..11] the root's traversal record, [16..] phase timestamps of the small-scene kernel
@@ -1029,7 +1382,7 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   int *result = (int *)pinned;
   const float *root = (const float *)(result + 4);
 
-  if (n <= kSmallUse) {
+  if (n <= small_use()) {
     // the whole build in one workgroup / one launch
     SmallArgs a{sph7_dev, n, (int)log2f((float)n) + 2, o, centres, (float4 *)(scratch + l.box4),
                 (int *)(scratch + l.v0), (int *)(scratch + l.trav), result};
@@ -1057,59 +1410,126 @@ hipError_t gpu_build_bvh(const float *sph7_dev, int n, const GpuBvhOut &o, char 
   float *bufmin = (float *)(scratch + l.bufmin), *bufmax = (float *)(scratch + l.bufmax);
   int *depth = (int *)(scratch + l.depth), *trav_of = (int *)(scratch + l.trav), *flags = (int *)(scratch + l.flags);
   // 1. centres, bounds, Morton keys
-  hipLaunchKernelGGL(centres_minmax_kernel, dim3(red_blocks), dim3(kBT), 0, st, sph7_dev, n, centres, partial);
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kBT), 0, st, partial, red_blocks, bounds);
-  hipLaunchKernelGGL(morton_kernel, dim3(nb_n), dim3(kBT), 0, st, centres, bounds, n, keys[0], vals[0]);
-  // 2. stable sort by the 30-bit key (15 passes of 2 bits)
-  int cur = 0;
-  for (int shift = 0; shift < 30; shift += kSortBits) {   // 8 passes of 4 bits
-    BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, counts, st));
-    cur ^= 1;
+  // (a CHAINED sort, for scenes of up to kSortRawBlocks sort tiles: no count launches, no launch for the bounds either;
+  // RANKED, up to kRankMaxN spheres: one launch per sort)
+  const int sort_blocks = cdiv(n, kSortTile), sort_blocks_i = cdiv(ni, kSortTile);
+  const bool ranked = n <= kRankMaxN, chained = !ranked && sort_blocks <= kSortRawBlocks;
+  unsigned *chain = (unsigned *)(scratch + l.chain);
+  auto chain_counts = [&](int pass) { return chain + (size_t)pass * kSortDigits * sort_blocks; };
+  if (ranked) {
+    hipLaunchKernelGGL(morton_all_kernel, dim3(nb_n), dim3(kBT), 0, st, sph7_dev, n, keys[0], flags);
+  } else {
+    hipLaunchKernelGGL(centres_minmax_kernel, dim3(red_blocks), dim3(kBT), 0, st, sph7_dev, n, centres, partial, chain,
+                       chained ? kChainPasses * kSortDigits * sort_blocks : 0, flags);
+    if (chained) {
+      hipLaunchKernelGGL(morton_chain_kernel, dim3(nb_n), dim3(kBT), 0, st, centres, partial, red_blocks, n, keys[0], vals[0], chain_counts(0),
+                         sort_blocks);
+    } else {
+      hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(kBT), 0, st, partial, red_blocks, bounds);
+      hipLaunchKernelGGL(morton_kernel, dim3(nb_n), dim3(kBT), 0, st, centres, bounds, n, keys[0], vals[0]);
+    }
   }
-  hipLaunchKernelGGL(gather_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, sph7_dev, vals[cur], n, o.L7);
-  // 3. radix tree over the sorted keys; 4. AABB propagation: exactly floor(log2 n) + 2 sweeps from all-zero boxes
+  // 2. stable sort by the 30-bit key: 8 passes of 4 bits
+  int cur = 0;
+  if (ranked) {
+    hipLaunchKernelGGL(rank_sort_kernel<false>, dim3(cdiv(n, kRankPerBlock)), dim3(kRankNT), rank_sort_lds_bytes(n), st, keys[0], n,
+                       keys[1], vals[1], (const int *)nullptr, (const int *)nullptr, (unsigned *)nullptr, (int *)nullptr);
+    cur = 1;
+  } else {
+    for (int shift = 0, pass = 0; shift < 30; shift += kSortBits, ++pass) {
+      if (chained)
+        BVH_HIP(sort_pass_chained(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, chain_counts(pass),
+                                  pass + 1 < kKeyPasses ? chain_counts(pass + 1) : nullptr, st));
+      else
+        BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, counts, st));
+      cur ^= 1;
+    }
+  }
+  // 3. sorted spheres, radix tree over the sorted keys; 4. AABB propagation: exactly floor(log2 n) + 2 sweeps from all-zero boxes
   const int sweeps = (int)log2f((float)n) + 2;
   float *pmin = bufmin, *pmax = bufmax, *cmin = o.bmin, *cmax = o.bmax;
-  if (sweeps % 2 == 0) {   // the last sweep must land in o.bmin / o.bmax
+  const bool fused = n <= kSweepFusedMaxN;
+  const int nlaunch = fused ? (sweeps + kSweepLevels - 1) / kSweepLevels : sweeps;
+  if (nlaunch % 2 == 0) {   // the last launch must land in o.bmin / o.bmax
     pmin = o.bmin; pmax = o.bmax; cmin = bufmin; cmax = bufmax;
   }
-  hipLaunchKernelGGL(build_fills_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, pmin, pmax, depth, ni);   // (fin[] borrows depth[], which is set later)
-  hipLaunchKernelGGL(radix_tree_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], n, o.left, o.right, o.parent);
-  for (int s = 0; s < sweeps; ++s) {
-    hipLaunchKernelGGL(aabb_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax,
-                       depth, s);
+  if (fused) {
+    if (ranked)
+      hipLaunchKernelGGL(tree_kernel<true>, dim3(nb_n), dim3(kBT), sizeof(unsigned) * (size_t)n, st, keys[cur], vals[cur], sph7_dev, n, o.L7, o.sph,
+                         o.col, o.left, o.right, o.parent);
+    else
+      hipLaunchKernelGGL(tree_kernel<false>, dim3(nb_n), dim3(kBT), 0, st, keys[cur], vals[cur], sph7_dev, n, o.L7, o.sph, o.col, o.left, o.right,
+                         o.parent);
+  } else {
+    hipLaunchKernelGGL(gather_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, sph7_dev, vals[cur], n, o.L7, o.sph, o.col);
+    hipLaunchKernelGGL(build_fills_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, pmin, pmax, depth, ni);   // (fin[] borrows depth[], which is set later)
+    hipLaunchKernelGGL(radix_tree_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], n, o.left, o.right, o.parent);
+  }
+  // (ranked: the first sweep launch also writes the depths, the key of the numbering below; the sorted keys are in keys[1] there)
+  const int *walk = ranked ? o.parent : nullptr;
+  for (int s = 0; s < sweeps;) {
+    const int k = fused ? (sweeps - s < kSweepLevels ? sweeps - s : kSweepLevels) : 1;
+#define RT_SWEEPK(K)                                                                                                                         \
+  case K:                                                                                                                                    \
+    if (s == 0)                                                                                                                              \
+      hipLaunchKernelGGL((aabb_sweepk_kernel<K, true>), dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax,    \
+                         walk, keys[0], flags + 1);                                                                                          \
+    else                                                                                                                                     \
+      hipLaunchKernelGGL((aabb_sweepk_kernel<K, false>), dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax,   \
+                         (const int *)nullptr, (unsigned *)nullptr, (int *)nullptr);                                                         \
+    break;
+    if (!fused) {
+      hipLaunchKernelGGL(aabb_sweep_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.L7, o.left, o.right, ni, pmin, pmax, cmin, cmax, depth, s);
+    } else {
+      switch (k) {
+        RT_SWEEPK(1) RT_SWEEPK(2) RT_SWEEPK(3) RT_SWEEPK(4) RT_SWEEPK(5)
+      }
+    }
+#undef RT_SWEEPK
+    s += k;
     float *t0 = pmin, *t1 = pmax;
     pmin = cmin; pmax = cmax; cmin = t0; cmax = t1;
   }
   // (after the loop pmin/pmax point at the newest boxes == o.bmin/o.bmax by the parity choice above)
   // 5./6. depths by walking up the parent links; traversal numbering: stable sort of the inner
   // nodes by depth
-  BVH_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
-  hipLaunchKernelGGL(depth_walk_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, keys[0], vals[0], flags + 1);
-  cur = 0;
-  for (int shift = 0; shift < 6; shift += kSortBits) {   // depth <= 30 key bits + 26 index bits < 64: 2 passes
-    BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], ni, shift, counts, st));
-    cur ^= 1;
-  }
-  hipLaunchKernelGGL(invert_kernel, dim3(nb_ni), dim3(kBT), 0, st, vals[cur], ni, trav_of);
-  // ... then treelet by treelet (treelet.h): sizes of the treelets in the order of their roots, their starts, the nodes' places
-  {
+  if (!ranked)
+    hipLaunchKernelGGL(depth_walk_kernel, dim3(nb_ni), dim3(kBT), 0, st, o.parent, ni, keys[0], vals[0], flags + 1,
+                       chained ? chain_counts(kKeyPasses) : nullptr, sort_blocks_i);
+  if (ranked) {
+    // ... one launch: the numbering by depth, its inverse, the treelet sizes; then the places (every block scans the sizes itself)
+    unsigned *size = (unsigned *)bufmin;      // (free since the sweeps: the newest boxes are in o.bmin / o.bmax)
+    int *place = depth, *order2 = vals[0];
+    hipLaunchKernelGGL(rank_sort_kernel<true>, dim3(cdiv(ni, kRankPerBlock)), dim3(kRankNT), rank_sort_lds_bytes(ni), st, keys[0], ni,
+                       keys[1], vals[1], o.left, o.right, size, trav_of);
+    hipLaunchKernelGGL(treelet_number_scan_kernel, dim3(cdiv(ni, kNumNT)), dim3(kNumNT), sizeof(unsigned) * 4 * kNumNT * (size_t)cdiv(ni, 4 * kNumNT), st,
+                       keys[0], size, trav_of, o.parent, o.left, o.right, ni, place, order2);
+    hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, order2, place, o.parent, o.left, o.right, o.bmin, o.bmax, ni, o.nodes32,
+                       o.nodes64, flags + 1, result);
+  } else {
+    cur = 0;
+    for (int shift = 0, pass = 0; shift < 6; shift += kSortBits, ++pass) {   // depth <= 30 key bits + 26 index bits < 64: 2 passes
+      if (chained)
+        BVH_HIP(sort_pass_chained(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], ni, shift, chain_counts(kKeyPasses + pass),
+                                  pass + 1 < kDepthPasses ? chain_counts(kKeyPasses + pass + 1) : nullptr, st));
+      else
+        BVH_HIP(sort_pass(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], ni, shift, counts, st));
+      cur ^= 1;
+    }
+    // ... then treelet by treelet (treelet.h): sizes of the treelets in the order of their roots, their starts, the nodes' places
     unsigned *start = keys[cur ^ 1];      // (free since the sort)
     int *place = depth, *order2 = vals[cur ^ 1];
     const int sb = cdiv(ni, kBT * kScanE);
-    hipLaunchKernelGGL(treelet_size_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], vals[cur], o.left, o.right, ni, start);
+    hipLaunchKernelGGL(treelet_size_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], vals[cur], o.left, o.right, ni, start, trav_of);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(sb), dim3(kBT), 0, st, start, ni, counts);
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kBT), 0, st, counts, sb);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(sb), dim3(kBT), 0, st, start, ni, counts);
     hipLaunchKernelGGL(treelet_number_kernel, dim3(nb_ni), dim3(kBT), 0, st, keys[cur], start, trav_of, o.parent, o.left, o.right, ni,
                        place, order2);
     hipLaunchKernelGGL(trav_nodes_kernel, dim3(nb_ni), dim3(kBT), 0, st, order2, place, o.parent, o.left, o.right, o.bmin, o.bmax, ni, o.nodes32,
-                       o.nodes64);
+                       o.nodes64, flags + 1, result);
   }
-  hipLaunchKernelGGL(trav_spheres_kernel, dim3(nb_n), dim3(kBT), 0, st, o.L7, n, o.sph, o.col);
   BVH_HIP(hipGetLastError());
-  BVH_HIP(hipMemcpyAsync(result, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-  BVH_HIP(hipMemcpyAsync(result + 4, o.nodes32, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
   BVH_HIP(hipStreamSynchronize(st));
   *height_out = result[0] + 1;   // levels of inner nodes == edges on the longest root -> leaf path
   for (int k = 0; k < 3; ++k) {

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""The chain of launches of the LAST prepare_scene in a rocprofv3 --kernel-trace CSV: start, duration, gap behind the previous kernel.
+usage: kt_chain.py <kernel_trace.csv> [first-kernel substring = centres_minmax]"""
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+first = sys.argv[2] if len(sys.argv) > 2 else "centres_minmax"
+idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+i0, prev = idx[-1], None
+t0 = int(rows[i0]["Start_Timestamp"])
+for r in rows[i0:]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].replace("void rtk::(anonymous namespace)::", "").replace("rtk::(anonymous namespace)::", "")[:44]
+    if prev is not None and s - prev > 30000: break      # the build is over: the next kernel belongs to a render
+    print("%-44s start %7.1f us  dur %5.1f  gap %5.1f  grid %s" % (name, (s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0, r.get("Grid_Size_X", "")))
+    prev = e
+print("chain: %.1f us" % ((prev - t0) / 1e3))

@@ -26,3 +26,20 @@ for name in ("rgbbox", "irreg"):
         ctx2.sync()
         ts.append(1e6 * (time.perf_counter() - t0))
     print("render", name, " ".join(f"{t:.0f}" for t in ts), "us")
+# prepare_scene against the number of spheres (random spheres in a box: every size class of the GPU builder)
+if len(sys.argv) > 1 and sys.argv[1] == "sizes":
+    rng = np.random.default_rng(5)
+    sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (3000, 6144, 6145, 8000, 10000, 15360, 15361, 20000, 40000, 90000, 131072, 131073, 300000, 1000000)
+    for n in sizes:
+        sph = np.empty((n, 7), np.float32)
+        sph[:, 0:3] = rng.uniform(-100, 100, (n, 3))
+        sph[:, 3:6] = rng.uniform(0, 1, (n, 3))
+        sph[:, 6] = rng.uniform(0.2, 1.5, n)
+        sc = ctx.scene_from_spheres(sph, (0, 0, 300), (0, 0, 0), 60.0)
+        ts = []
+        for i in range(8):
+            t0 = time.perf_counter()
+            ps = api.prepare_scene(200, 200, sc)
+            ctx.sync()
+            ts.append(1e6 * (time.perf_counter() - t0))
+        print(f"n={n} height={ps.height if hasattr(ps, 'height') else '?'}", " ".join(f"{t:.0f}" for t in ts), "us")
