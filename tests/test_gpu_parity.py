@@ -47,10 +47,12 @@ def _scene(ctx, scene):
 # ---------------------------------------------------------------- BVH + camera ------------
 @pytest.mark.parametrize("gpu_build", [1, 0])
 @pytest.mark.parametrize("scene", ["rgbbox", "irreg", "floor:37:222", "floor:2:12", "floor:300:1800",
-                                   # the builder's size boundaries: 1 / 3 elements per thread in the one-workgroup
-                                   # sort, the largest scene it is used for (6084 <= 6144 spheres) and the smallest
-                                   # multi-kernel one (6241), and either side of the one-workgroup kernel's capacity (16384)
-                                   "floor:32:192", "floor:33:198", "floor:78:468", "floor:79:474", "floor:128:768", "floor:129:774"])
+                                   # the builder's size boundaries: the largest scene of the one-workgroup build (729 <= 768 spheres)
+                                   # and the smallest of the ranked chain (784); ranked sizes of 1 / 2 / 12 / 32 keys per thread of
+                                   # the ranking kernel; the largest ranked scene (24 336 <= 24 576) and the smallest with chained
+                                   # sort passes (24 649); the largest with fused sweeps (131 044 <= 131 072) and the smallest without
+                                   "floor:27:162", "floor:28:168", "floor:32:192", "floor:33:198", "floor:78:468", "floor:79:474",
+                                   "floor:128:768", "floor:129:774", "floor:156:936", "floor:157:942", "floor:362:2172", "floor:363:2178"])
 def test_bvh_arrays_bit_exact(R, ctx, scene, gpu_build):
     """prepare_scene's {L, I} (bvh.fut:28) from the GPU builder (bvh_build.hip) and from the
     host builder, both against the oracle: spheres, child pointers, parents and boxes bit-exact."""
@@ -526,11 +528,13 @@ def test_random_scene_with_duplicates_and_explicit_camera(R, ctx):
         assert int((px2 != ref2).sum()) == 0
 
 
-@pytest.mark.parametrize("n,kind", [(2, "apart"), (3, "apart"), (2, "same"), (5, "same"), (64, "same"), (65, "line")])
+@pytest.mark.parametrize("n,kind", [(2, "apart"), (3, "apart"), (2, "same"), (5, "same"), (64, "same"), (65, "line"),
+                                    (2000, "same"), (3000, "line"), (20000, "same")])
 def test_tiny_and_degenerate_scenes(R, ctx, n, kind):
     """The smallest trees (one or two inner nodes), all spheres identical (every Morton key equal:
     the radix tree falls back to the index tie-break at every level), and a flat line of spheres
-    (two degenerate Morton axes: 0/0 = NaN quantised to 0)."""
+    (two degenerate Morton axes: 0/0 = NaN quantised to 0).  The sizes in the thousands go through
+    the ranked chain: all keys equal is ONE bucket holding everything, the ranking kernel's slowest case."""
     s = np.zeros((n, 7), np.float32)
     s[:, 3:6] = np.linspace(0.3, 1.0, 3 * n, dtype=np.float32).reshape(n, 3)
     s[:, 6] = 2.0
@@ -539,19 +543,20 @@ def test_tiny_and_degenerate_scenes(R, ctx, n, kind):
     elif kind == "line":
         s[:, 0] = np.arange(n, dtype=np.float32) * 1.5 - 40.0
     lf, la, fov = (0.0, 3.0, 30.0), (0.0, 0.0, 0.0), 50.0
+    h, w = (72, 96) if n <= 100 else (24, 32)      # (thousands of spheres in one place: every ray that hits tests them all)
     orc = O.OracleScene("custom", spheres7=s, look_from=lf, look_at=la, fov=fov)
     for gpu_build in (1, 0):
         ctx.set_option("gpu_build", gpu_build)
-        ps = R.prepare_scene(72, 96, ctx.scene_from_spheres(s, lf, la, fov))
+        ps = R.prepare_scene(h, w, ctx.scene_from_spheres(s, lf, la, fov))
         got, want = ps.bvh_arrays(), orc.arrays()
         for k in ("left", "right", "parent"):
             assert (got[k] == want[k]).all(), (k, gpu_build)
         for k in ("L", "bmin", "bmax"):
             assert got[k].tobytes() == want[k].tobytes(), (k, gpu_build)
-        ref, _ = orc.render(72, 96)
+        ref, _ = orc.render(h, w)
         for variant in (1, 2, 3):
             ctx.set_variant(variant)
-            assert int((R.render(72, 96, ps) != ref).sum()) == 0, (variant, gpu_build)
+            assert int((R.render(h, w, ps) != ref).sum()) == 0, (variant, gpu_build)
     ctx.set_option("gpu_build", 1)
     ctx.set_variant(0)
 
