@@ -38,7 +38,18 @@ namespace {
 
 // ---- device-block pool -------------------------------------------------------------------------
 constexpr size_t kPoolMaxBlocks = 8, kPoolMaxBlockBytes = size_t(256) << 20;
-constexpr size_t kGranule = size_t(64) << 10, kArenaGranules = 256;   // 16 MiB arena per context
+// RT_TICKS=1 (a measurement aid): host microseconds between the stages of a render call, on stderr
+struct Ticks {
+  bool on = std::getenv("RT_TICKS") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void operator()(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  [tick] %-28s +%.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+    t = n;
+  }
+};
+constexpr size_t kGranule = size_t(64) << 10, kArenaGranules = 2048;   // 128 MiB arena per context (views' blocks, tables, the Futhark ABI's images)
 constexpr size_t kStageBytes = size_t(1) << 20;
 
 hipError_t pool_alloc(rt_context *ctx, char **out, size_t *bytes_io) {
@@ -541,9 +552,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     ctx->last_launch = "family=none (memset)";
     return 0;
   }
+  Ticks tick;
   Plan pl{};
   if (stats) pl.variant = RT_VARIANT_PIXEL;
   else if (int rc = make_plan(ctx, ps, &pl, static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8) * nframes)) return rc;
+  tick("plan");
   if (nframes > 1 && pl.variant != RT_VARIANT_POOLED) {
     // only the pooled family renders a batch in one launch: the others take the frames one by one
     std::vector<float> hc;
@@ -602,6 +615,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (ps->n >= (int64_t(1) << 22)) return fail(ctx, "pooled kernel: at most 2^22 spheres (work items and hit keys carry the leaf index in 22 bits)");
     if (p.rpt_log2 < 0) return fail(ctx, "pooled kernel: rows_per_tile must be a power of two");
     if (int rc = get_uv(ctx, w, h, &p.u_tab, &p.v_tab)) return rc;
+    tick("uv tables");
     // May a view of this shape ever render through a pixel list (the ORD launch condition's static part)?  Only then does it get the
     // per-pixel buffers (5 bytes per pixel) and does its first frame store the per-pixel record.
     const bool px_static_ok = ctx->pixel_order == 2 ||
@@ -787,7 +801,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     if (ctx->first_order && nframes == 1 && p.order == nullptr && !p.px_hdr && (p.nshards == 1 || p.interleave) && p.tiles_y > 1 &&
         p.tiles_y <= 4096 && p.tiles_x <= 32768) {
       // a frame nothing is known about: not top to bottom (the kernel reads the table like a view's order, with no deep tiles)
+      tick("view, sorts, borrow");
       if (int rc = get_first_order(ctx, p.tiles_x, p.tiles_y, &p.order)) return rc;
+      tick("first order");
       p.deep_class = 0;
       first_order = true;
     }
@@ -799,7 +815,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       p.cull_c2 = ps->cull.c2;
       p.cull_kappa = ps->cull.kappa;
     }
+    tick("before launch");
     RT_HIP(ctx, rtk::launch_pooled(p, false, pl.grid, pl.waves, ctx->stream));
+    tick("launch_pooled");
     {
       // (which instantiation launch_pooled picks, in its own order of precedence)
       const bool single_px = p.solo && p.nframes == 1 && p.order != nullptr && p.deep_class > 0 && p.deep_split == 6 && p.tl_log2 == rtk::kTreeletDepth;
@@ -824,6 +842,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       // new view can borrow this one's order at once)
       if (ctx->eager_sort && (stream_was_idle || ctx->sync_policy))
         if (int rc = sort_view(ctx, ps, to, p, pl)) return rc;
+      tick("record: eager sorts");
     }
   }
   else {
@@ -893,6 +912,7 @@ extern "C" int rt_context_create(rt_context **out, int device, void *hip_stream,
   if (hipHostMalloc(reinterpret_cast<void **>(&ctx->class_slab), sizeof(int) * kClassSlotInts * kClassSlots * kClassChunks, hipHostMallocDefault) != hipSuccess) return bail(7);
   rtk::warm_render_kernels();
   rtk::warm_build_kernels();
+  if (rtk::warm_scratch(ctx->stream, ctx->order_scratch) != hipSuccess) return bail(6);
   if (const char *v = std::getenv("RT_VARIANT")) ctx->variant = std::atoi(v);
   // (test aids: the whole suite under the other queue layouts)
   if (const char *v = std::getenv("RT_XCD_QUEUES")) ctx->xcd_queues = std::max(-1, std::min(2, std::atoi(v)));
@@ -1708,7 +1728,8 @@ struct futhark_context {
   rt_context *rt = nullptr;
   // freed images are kept for reuse: main.c frees and re-renders every run, and a
   // hipFree/hipMalloc pair per frame costs more than the frame itself
-  std::vector<std::pair<int64_t, int32_t *>> image_pool;
+  struct PooledImage { int64_t elems; int32_t *dev; size_t block_bytes; };
+  std::vector<PooledImage> image_pool;
   std::string pending;   // error not yet collected by futhark_context_get_error
   int logging = 0;
   uint64_t renders = 0, prepares = 0;
@@ -1722,7 +1743,29 @@ struct futhark_opaque_prepared_scene {
 struct futhark_i32_2d {
   int32_t *dev = nullptr;
   int64_t shape[2] = {0, 0};
+  size_t block_bytes = 0;   // != 0: a block of the context's arena / block pool (image_alloc); 0: rt_device_alloc's
 };
+namespace {
+// An entry point's result array from the context's arena (pool_alloc): a hipMalloc of 4 MB inside the harness's first render call was ~0.1 ms
+// of its first frame.  Freed (image_release) behind a drained stream, like rt_device_free.
+int image_alloc(rt_context *ctx, void **dev, size_t *block_bytes, int64_t bytes) {
+  RT_LOCK(ctx);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  char *blk = nullptr;
+  *block_bytes = static_cast<size_t>(std::max<int64_t>(bytes, 16));
+  RT_HIP(ctx, pool_alloc(ctx, &blk, block_bytes));
+  *dev = blk;
+  return 0;
+}
+int image_release(rt_context *ctx, void *dev, size_t block_bytes) {
+  if (!block_bytes) return rt_device_free(ctx, dev);
+  RT_LOCK(ctx);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pool_free(ctx, static_cast<char *>(dev), block_bytes);
+  return 0;
+}
+}  // namespace
 
 #ifndef RT_NO_CONTEXT_LOCK
 #define FUT_LOCK(ctx) std::unique_lock<std::recursive_mutex> fut_lock_ = (ctx) ? std::unique_lock<std::recursive_mutex>((ctx)->mu) : std::unique_lock<std::recursive_mutex>()
@@ -1789,7 +1832,7 @@ extern "C" struct futhark_context *futhark_context_new(struct futhark_context_co
 }
 extern "C" void futhark_context_free(struct futhark_context *ctx) {
   if (!ctx) return;
-  for (auto &e : ctx->image_pool) rt_device_free(ctx->rt, e.second);
+  for (auto &e : ctx->image_pool) (void)image_release(ctx->rt, e.dev, e.block_bytes);
   rt_context_destroy(ctx->rt);
   delete ctx;
 }
@@ -1854,18 +1897,19 @@ extern "C" int futhark_entry_render(struct futhark_context *ctx, struct futhark_
   auto img = std::make_unique<futhark_i32_2d>();
   void *dev = nullptr;
   for (size_t i = 0; i < ctx->image_pool.size(); ++i)
-    if (ctx->image_pool[i].first == in0 * in1) {
-      dev = ctx->image_pool[i].second;   // same stream => the new frame orders after any pending use
+    if (ctx->image_pool[i].elems == in0 * in1) {
+      dev = ctx->image_pool[i].dev;   // same stream => the new frame orders after any pending use
+      img->block_bytes = ctx->image_pool[i].block_bytes;
       ctx->image_pool.erase(ctx->image_pool.begin() + static_cast<long>(i));
       break;
     }
   if (!dev)
-    if (int rc = rt_device_alloc(ctx->rt, &dev, static_cast<int64_t>(sizeof(int32_t)) * in0 * in1)) return fut_fail(ctx, rc);
+    if (int rc = image_alloc(ctx->rt, &dev, &img->block_bytes, static_cast<int64_t>(sizeof(int32_t)) * in0 * in1)) return fut_fail(ctx, rc);
   img->dev = static_cast<int32_t *>(dev);
   img->shape[0] = in0;
   img->shape[1] = in1;
   if (int rc = rt_render(ctx->rt, in2->p, in0, in1, img->dev)) {
-    rt_device_free(ctx->rt, dev);
+    (void)image_release(ctx->rt, dev, img->block_bytes);
     return fut_fail(ctx, rc);
   }
   ctx->renders++;
@@ -1882,8 +1926,8 @@ extern "C" int futhark_free_i32_2d(struct futhark_context *ctx, struct futhark_i
   if (!arr) return 0;
   int rc = 0;
   if (ctx && ctx->rt && arr->dev) {
-    if (ctx->image_pool.size() < 4) ctx->image_pool.emplace_back(arr->shape[0] * arr->shape[1], arr->dev);
-    else rc = rt_device_free(ctx->rt, arr->dev);
+    if (ctx->image_pool.size() < 4) ctx->image_pool.push_back({arr->shape[0] * arr->shape[1], arr->dev, arr->block_bytes});
+    else rc = image_release(ctx->rt, arr->dev, arr->block_bytes);
   }
   delete arr;
   return fut_fail(ctx, rc);
@@ -1907,7 +1951,7 @@ extern "C" int futhark_context_clear_caches(struct futhark_context *ctx) {
   FUT_LOCK(ctx);
   if (!ctx || !ctx->rt) return 1;
   if (rt_context_sync(ctx->rt)) return fut_fail(ctx, 1);
-  for (auto &im : ctx->image_pool) (void)rt_device_free(ctx->rt, im.second);
+  for (auto &im : ctx->image_pool) (void)image_release(ctx->rt, im.dev, im.block_bytes);
   ctx->image_pool.clear();
   for (auto &b : ctx->rt->pool) (void)hipFree(b.p);
   ctx->rt->pool.clear();

@@ -1587,18 +1587,20 @@ __global__ __launch_bounds__(256) void first_order_rank_kernel(int tiles_x, int 
     rank[tiles_y + q] = off;
   }
 }
-__global__ void first_order_fill_kernel(int tiles_x, int tiles_y, const int *rank, int *order) {
+// (... and zeroes the class tables behind the permutation: order[ntiles .. total) -- a memset's two or three fill dispatches ahead of a context's first frame)
+__global__ void first_order_fill_kernel(int tiles_x, int tiles_y, const int *rank, int *order, int total) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= tiles_x * tiles_y) return;
+  const int ntiles = tiles_x * tiles_y;
+  for (int z = ntiles + t; z < total; z += gridDim.x * blockDim.x) order[z] = 0;
+  if (t >= ntiles) return;
   const int r = t / tiles_x, x = t - r * tiles_x;
   order[rank[r] * tiles_x + rank[tiles_y + (x >> 3)] + (x & 7)] = t;
 }
 // `order`: order_table_ints(tiles) ints (the permutation, then zeroed class tables); `rank`: tiles_y + ceil(tiles_x / 8) ints of scratch
 hipError_t launch_first_order(int *order, int *rank, int tiles_x, int tiles_y, hipStream_t stream) {
   const int ntiles = tiles_x * tiles_y, nb = (tiles_x + 7) / 8;
-  if (hipError_t e = hipMemsetAsync(order + ntiles, 0, sizeof(int) * (size_t)(order_table_ints(ntiles) - ntiles), stream); e != hipSuccess) return e;
   hipLaunchKernelGGL(first_order_rank_kernel, dim3((tiles_y + nb + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank);
-  hipLaunchKernelGGL(first_order_fill_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank, order);
+  hipLaunchKernelGGL(first_order_fill_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, tiles_x, tiles_y, rank, order, order_table_ints(ntiles));
   return hipGetLastError();
 }
 

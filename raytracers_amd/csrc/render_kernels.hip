@@ -1801,6 +1801,22 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
 
 // Loads this file's code object and resolves the default kernels (HIP loads modules lazily, at
 // the first launch: ~0.5 ms that would otherwise land in the first timed frame).
+// The instantiations that CALL solo_trace (a real function: SOLO, COLD, DONATE) need a private segment -- 8 bytes per lane, the callee's
+// saved register -- and the first dispatch of a queue that needs scratch waits for the runtime to allocate it: ~0.1 ms inside a context's first
+// frame (its first launch is a DONATE instantiation).  warm_scratch puts that wait into context creation: a do-nothing kernel with a larger
+// private segment, as many waves as the device holds, on the context's stream.
+__global__ __launch_bounds__(64) void scratch_warm_kernel(int *sink, int k) {
+  volatile int a[8];
+  a[k & 7] = k;
+  a[(k + 1) & 7] = 1;
+  if (a[(k + 2) & 7] == 0x5ca7c4) *sink = 1;
+}
+hipError_t warm_scratch(hipStream_t stream, int *sink_dev) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipLaunchKernelGGL(scratch_warm_kernel, dim3(cus * 32), dim3(64), 0, stream, sink_dev, 1);
+  return hipGetLastError();
+}
 void warm_render_kernels() {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false>);

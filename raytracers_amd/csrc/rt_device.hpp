@@ -277,6 +277,7 @@ struct GpuBvhOut {
   float4 *sph, *col;         // [n]
 };
 void warm_render_kernels();
+hipError_t warm_scratch(hipStream_t stream, int *sink_dev);   // the queue's scratch allocated now, not inside the first frame
 void warm_build_kernels();
 size_t gpu_build_scratch_bytes(int n);   // device scratch one build of n spheres needs
 hipError_t gpu_copy_from_pinned(void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t stream);
