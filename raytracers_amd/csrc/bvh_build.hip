@@ -4,13 +4,14 @@
 //
 //   centres + min/max   bvh.fut:31-37     (fmin/fmax reductions: order-free for non-NaN input)
 //   Morton keys         bvh.fut:38-41, :8-22   (IEEE division, fmax(NaN, 0) = 0 on a flat axis)
-//   stable sort by key  bvh.fut:43        LSD radix, 2 bits per pass like radix_sort.fut:14-32
+//   stable sort by key  bvh.fut:43        = the sort by (key, index): by RANKING in one launch (mid sizes), else LSD radix passes of 4 bits
 //   radix tree          radixtree.fut:23-72    one thread per inner node, pure integer
-//   AABB propagation    bvh.fut:44-58     EXACTLY floor(log2 n)+2 double-buffered Jacobi sweeps
-//   traversal copy      nodes renumbered by depth (root levels first = the LDS-staged prefix)
+//   AABB propagation    bvh.fut:44-58     EXACTLY floor(log2 n)+2 double-buffered Jacobi sweeps (three composed per launch where launches are the cost)
+//   traversal copy      nodes renumbered by depth, treelet by treelet (root levels first = the LDS-staged prefix)
 //
-// Everything is enqueued on the caller's stream; the only host round trips are the
-// "did any depth change" flag (once per 8 sweeps) and the final tree height.
+// Four size classes: n <= kSmallUse one workgroup, one launch; <= kRankMaxN the RANKED chain of 11 launches; <= kSweepFusedMaxN radix
+// passes without count launches + fused sweeps; beyond, a launch per phase and sweep.  Everything is enqueued on the caller's stream; the one host
+// round trip is the final synchronisation (tree height and root record arrive in the pinned report block, stored by the last kernel).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -1279,7 +1280,7 @@ __global__ __launch_bounds__(kSmallNT) void bvh_small_kernel(SmallArgs a) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// one stable 2-bit LSD pass over (keys, vals): in -> out
+// one stable LSD pass of kSortBits bits over (keys, vals): in -> out
 hipError_t sort_pass(const unsigned *kin, const int *vin, unsigned *kout, int *vout, int n, int shift, unsigned *counts,
                      hipStream_t st) {
   const int nblocks = cdiv(n, kBT * kSortE);
