@@ -900,9 +900,9 @@ __global__ __launch_bounds__(kBT) void trav_nodes_kernel(const int *order, const
 // the traversal numbering live in LDS (2 x 4n bytes <= 128 KB); boxes stay in global memory (L2).
 constexpr int kSmallNT = 1024;
 constexpr int kSmallMax = 16384;   // digit totals fit the packed 16-bit counters
-// ... and it is USED up to kSmallUse spheres: one workgroup takes 0.079 ms at 400 spheres, 0.093 at 1000, 0.125 at 2000, 0.26 at 6144; the ranked
-// chain of 11 launches 0.074-0.080 / 0.084 / 0.091 / 0.110 (profiles/r06/exp/e8_prepare_sizes.txt; until round 6 the chain was ~45 launches,
-// 0.25 ms, and the crossover 6144)
+// ... and it is USED up to kSmallUse spheres: one workgroup takes 0.062 ms at 400 spheres and 0.076 at 768 (its key sort by ranking, small_sort), the ranked
+// chain of 11 launches 0.074-0.080 / 0.083; at 800 .. 1024 the two are level, beyond 1024 the one workgroup sorts by LSD passes again: 0.125 ms at 2000, 0.26 at
+// 6144 against 0.091 / 0.110 (profiles/r06/exp/e8_prepare_sizes.txt; until round 6 the chain was ~45 launches, 0.25 ms, and the crossover 6144)
 constexpr int kSmallUse = 768;
 inline int small_use() {          // (RT_BVH_SMALL_USE: a measurement aid, the crossover between the one-workgroup build and the ranked chain)
   static const int v = [] {
@@ -938,7 +938,46 @@ __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v) {
 // Stable LSD sort of (lk[i], lv[i]), i < m, by key bits [0, bits): 2 bits per pass.  Thread t owns
 // elements [t*E, (t+1)*E) in registers between passes; LDS is the exchange buffer.  Digit counts
 // travel as four 16-bit fields (two per dword: m <= 16384, so no field ever carries).
+// (m <= kSmallNT, which is every scene this kernel is USED for since round 6: by ranking -- a thread per element counts the (key, index) pairs below its
+// own over the m keys in LDS, read at wave-uniform addresses; rgbbox, 400 keys: 6.8 us where 15 passes took 25, prepare_scene 0.082 -> 0.060 ms)
 __device__ __forceinline__ void small_sort(unsigned *lk, unsigned *lv, int m, int bits) {
+  if (m <= kSmallNT && bits > 8) {      // (a 6-bit key -- the depths -- is three cheap passes below)
+    const int t = threadIdx.x;
+    const unsigned k = t < m ? lk[t] : 0u, v = t < m ? lv[t] : 0u;
+    unsigned r = 0;
+    const int w0 = t & ~63;               // this wave's elements are [w0, w0 + 64)
+    if (w0 < m) {                         // (a wave without elements only keeps the barriers)
+      int j = 0;
+      for (; j + 16 <= m; j += 16) {      // 16 keys per step: four 16-byte reads in flight, at wave-uniform addresses
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const uint4 *>(lk + j)[u];
+        if (j + 16 <= w0 || j >= w0 + 64) {       // all 16 before (key <= k counts) or behind (key < k) every element of the wave: one compare per pair
+          const unsigned thr = k + (j < w0 ? 1u : 0u);      // keys < 2^30: no wrap
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r += (q[u].x < thr ? 1u : 0u) + (q[u].y < thr ? 1u : 0u) + (q[u].z < thr ? 1u : 0u) + (q[u].w < thr ? 1u : 0u);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned kk[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r += (kk[e] < k || (kk[e] == k && j + 4 * u + e < t)) ? 1u : 0u;
+          }
+        }
+      }
+      for (; j < m; ++j) {
+        const unsigned kj = lk[j];
+        r += (kj < k || (kj == k && j < t)) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (t < m) {
+      lk[r] = k;
+      lv[r] = v;
+    }
+    __syncthreads();
+    return;
+  }
   __shared__ uint2 wave_tot[2][kSmallNT / 64];
   const int E = ((m + kSmallNT - 1) / kSmallNT) | 1;   // odd: conflict-free stride
   const int base = threadIdx.x * E;
