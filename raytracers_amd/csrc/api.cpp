@@ -175,7 +175,9 @@ struct Plan {
 // `ntiles`: 8x8 tiles of the launch (grid_div == 0 picks the launch size from it: up to ~1000x1000 a
 // half-size launch keeps the waves better filled -- 5-18 % per frame --, larger frames want every wave).
 // `force_waves` != 0: only workgroups of that many waves (the instrumented instantiation has 8).
-int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, int force_waves = 0) {
+// `wide`: the launch may take the shape of FIVE workgroups of four waves per CU (a batch, or a frame too large for a pixel list): five waves
+// per SIMD for scenes that are read from L2 (the plain and CULL kernels only; trees of height <= 15: a wave's region must fit a twentieth of the LDS).
+int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, int force_waves = 0, bool wide = false) {
   const bool auto_variant = ctx->variant == RT_VARIANT_AUTO;
   pl->variant = ctx->variant;
   if (auto_variant) pl->variant = ps->n < (int64_t(1) << 22) ? RT_VARIANT_POOLED : RT_VARIANT_PIXEL;
@@ -194,6 +196,11 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   pl->smax = smax;
   pl->lmax = ctx->lmax;
   // pooled family: box stack <= 64*H + 128 items (see the kernel's header), leaf list <= 63 + 128
+  // (the shapes of twenty waves per CU: 64 * (H + 2) -- what is provable: a SHADE finds at most 63 items and adds at most 64 roots; the blocks
+  // pushed behind it have strictly increasing minimum depths 1 .. H - 1, every block but the top one holds at most 64 items, the top one at
+  // most 128: 63 + 64 (H - 2) + 128 = 64 H + 63 items)
+  struct Shape { int wgs, waves, planes; };
+  auto capb_of = [&](const Shape &sh) { return 64 * (ps->height + (sh.wgs * sh.waves == 20 ? 2 : 3)); };
   pl->capb = 64 * (ps->height + 3);
   pl->capl = 192;
   // Workgroup shape {workgroups per CU, waves per workgroup}.  The per-wave scratch grows with the
@@ -204,7 +211,6 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   // (pooled family: a shape also says whether the wave's ray table keeps the {d} plane -- 1 KB per wave that
   // lets LEAF read the direction with one ds_read_b128 instead of three ds_bpermute; dropping it is what fits
   // 16 waves next to the whole rgbbox scene)
-  struct Shape { int wgs, waves, planes; };
   std::vector<Shape> shapes;
   const int pl_cfg = ctx->ray_planes == 2 || ctx->ray_planes == 3 ? ctx->ray_planes : 0;
   auto add = [&](int wgs, int waves) {
@@ -223,8 +229,11 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   const int node_bytes = pooled ? 64 : 32;
   const int64_t scene_bytes = static_cast<int64_t>(ni) * node_bytes + static_cast<int64_t>(n) * 16;
   auto budget_of = [&](const Shape &sh) {
+    // (five workgroups per CU: the LDS is handed out in blocks of 1280 bytes -- 25 of the 128 each, measured: a workgroup of 32 256 bytes
+    // is resident four times, one of 31 808 five times, profiles/r06/exp/e11 -- and the shape stages no scene prefix at all)
+    if (sh.wgs == 5) return pooled && sh.waves * rtk::pooled_wave_dw(sh.planes, capb_of(sh), pl->capl) * 4 <= 25 * 1280 && ctx->lds_bytes >= 160 * 1024 ? 0 : -1;
     const int total = std::min(ctx->lds_bytes, 160 * 1024) / sh.wgs;
-    const int scratch = pooled ? sh.waves * rtk::pooled_wave_dw(sh.planes, pl->capb, pl->capl) * 4
+    const int scratch = pooled ? sh.waves * rtk::pooled_wave_dw(sh.planes, capb_of(sh), pl->capl) * 4
                                : sh.waves * (pl->smax + 1 + pl->lmax) * 64 * 4;
     return total - scratch - 512;
   };
@@ -234,6 +243,13 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   if (pick < 0)
     for (size_t i = 0; i < shapes.size() && pick < 0; ++i)
       if (budget_of(shapes[i]) >= scene_bytes) pick = static_cast<int>(i);
+  if (pick < 0 && wide && pooled && !force_waves && !configured) {   // the scene does not fit in LDS: five waves per SIMD if they fit
+    const Shape sh{5, 4, 2};
+    if (budget_of(sh) >= 0) {
+      shapes.push_back(sh);
+      pick = static_cast<int>(shapes.size()) - 1;
+    }
+  }
   if (pick < 0)
     for (size_t i = 0; i < shapes.size() && pick < 0; ++i)
       if (budget_of(shapes[i]) >= 0) pick = static_cast<int>(i);
@@ -244,6 +260,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   const int wgs = shapes[static_cast<size_t>(pick)].wgs;
   pl->waves = shapes[static_cast<size_t>(pick)].waves;
   pl->ray_planes = shapes[static_cast<size_t>(pick)].planes;
+  pl->capb = capb_of(shapes[static_cast<size_t>(pick)]);
   int budget = budget_of(shapes[static_cast<size_t>(pick)]);
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   int ln, ls;
@@ -470,7 +487,7 @@ void drain_streams(rt_context *ctx) {
 // exist for, and every camera origin of the launch inside the scene guard -- a batch's cameras are read from the context's pinned
 // copy of them (stage_cams); cameras that live only on the device switch culling off.
 bool cull_allowed(const rt_context *ctx, const rt_prepared *ps, const Plan &pl, const rtk::KParams &p, const float *cams_dev, int nframes) {
-  if (ctx->cull == 0 || !ps->cull.ok || pl.variant != RT_VARIANT_POOLED || pl.waves != 16) return false;
+  if (ctx->cull == 0 || !ps->cull.ok || pl.variant != RT_VARIANT_POOLED || (pl.waves != 16 && pl.waves != 4)) return false;
   if (ctx->cull < 0 && pl.lds_nodes == p.n_nodes && pl.lds_sph == p.n_sph) return false;
   if (cams_dev == nullptr) return rt::cull_origin_ok(ps->cull, &p.cam.ox);
   if (cams_dev != ctx->cams_dev || ctx->cams_host == nullptr) return false;
@@ -555,7 +572,14 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   Ticks tick;
   Plan pl{};
   if (stats) pl.variant = RT_VARIANT_PIXEL;
-  else if (int rc = make_plan(ctx, ps, &pl, static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8) * nframes)) return rc;
+  else {
+    const int64_t ntiles1 = static_cast<int64_t>((w + 7) / 8) * ((p.rows_local + 7) / 8);
+    // (twenty waves per CU: batches and frames of 100 000 tiles or more -- launches bound by their work.  Measured, profiles/r06/exp/e11: irreg's batch of 20
+    // frames of 1000 x 1000 0.110 -> 0.104 ms per frame, one frame of 4000 x 4000 1.72 -> 1.63 ms, 2000 x 2000 -- 62 500 tiles -- the same; single frames
+    // within the pixel list's range keep the 16-wave kernels, whose ORD / SOLO / DONATE instantiations they are rendered by)
+    const bool wide = ctx->wide_waves == 2 || (ctx->wide_waves == 1 && ntiles1 * nframes >= 100000 && (nframes > 1 || ntiles1 > ctx->px_max_tiles));
+    if (int rc = make_plan(ctx, ps, &pl, ntiles1 * nframes, 0, wide)) return rc;
+  }
   tick("plan");
   if (nframes > 1 && pl.variant != RT_VARIANT_POOLED) {
     // only the pooled family renders a batch in one launch: the others take the frames one by one
@@ -587,7 +611,10 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   // tiles per wave -- fewer when a launch is small: a rank's eighth of those frames is 10-20 tiles per wave, and with four per
   // ticket the waves' loads differ by whole tickets)
   const int64_t tiles_per_wave = static_cast<int64_t>(p.nchunks) * nframes / std::max(1, pl.grid * pl.waves);
-  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (nframes > 1 ? (tiles_per_wave >= 48 ? 2 : tiles_per_wave >= 24 ? 1 : 0) : 0);
+  // (twenty waves per CU: two tiles per ticket at most, and the look from 16 items down -- a wave there has a quarter of a SIMD's issue slots
+  // less and waits longer for each of its loads; irreg's batch 0.104 -> 0.101-0.103 ms per frame, a floor of 6 400 spheres 0.101 -> 0.096, profiles/r06/exp/e11)
+  const bool twenty = pl.waves * (pl.grid_full / std::max(1, ctx->num_cu)) == 20;
+  p.tpt_log2 = ctx->tpt_log2 >= 0 ? ctx->tpt_log2 : (nframes > 1 ? (tiles_per_wave >= 48 && !twenty ? 2 : tiles_per_wave >= 24 ? 1 : 0) : 0);
   // Eight ticket counters (one per XCD: workgroup b runs on XCD b % 8).  Default: they take turns over ONE queue (counter
   // s hands out tickets s, s + 8, ...): the adaptive order stays global and one word no longer carries every draw --
   // measured against one counter: irreg 1000x1000 -8 %, 4000x4000 -38 %, the 10^6-sphere frame -18 %, rgbbox +-1 %.
@@ -608,7 +635,7 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.box2 = ctx->box2;
   // (batches, and launches of more than 16 384 tiles -- frames beyond 1000 x 1000 and a rank's share of a 4000 x 4000 one: -1.8 .. -3.6 %
   // with 32, profiles/r04/exp/e10, e11; a 1000 x 1000 frame is the same within +-1 % either way and keeps 64)
-  p.look_max = ctx->look_max > 0 ? ctx->look_max : ((nframes > 1 || p.nchunks > 16384) ? 32 : 64);
+  p.look_max = ctx->look_max > 0 ? ctx->look_max : (twenty ? 16 : (nframes > 1 || p.nchunks > 16384) ? 32 : 64);
   p.tl_log2 = ps->tl_depth;
   p.solo = ctx->solo;
   if (pl.variant == RT_VARIANT_POOLED) {
@@ -1092,6 +1119,8 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->eager_sort = v != 0;
   } else if (k == "borrow") {
     ctx->borrow = std::max(0, std::min(4, v));
+  } else if (k == "wide_waves") {
+    ctx->wide_waves = std::max(0, std::min(2, v));
   } else if (k == "cull") {
     ctx->cull = std::max(-1, std::min(1, v));
   } else if (k == "sync_policy") {

@@ -599,8 +599,13 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // CULL: boxes are tested against the slot's best root so far instead of the fixed 1e9 (lane_core.h: cull_limit) -- a
 // subtree whose every root is proven larger than a root already found is not walked.  Same pixels (the fold's RESULT is the contract,
 // ray.fut:76-86), fewer tests: irreg 1000 x 1000 -15 % box tests, -36 % sphere tests in this kernel's order (tools/cull_pooled.cpp).
+// THREADS == 256 (round 6): the shape of FIVE workgroups of four waves per CU -- five waves per SIMD instead of four -- for scenes that are
+// read from L2: their frames are bound by how much latency the resident waves hide.  The second launch-bounds argument makes the register
+// allocator stay within the 96 VGPRs five waves per SIMD leave each (the 16-wave kernels hold 99-101; the difference is one dword spilled
+// in SHADE).  (Two workgroups of ten waves do not do it: a workgroup's waves go to the SIMDs round robin from SIMD 0, ten waves are 3 3 2 2,
+// and a second workgroup would need six wave slots of 96 VGPRs on SIMD 0 -- it never becomes resident: measured, profiles/r06/exp/e11.)
 template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false>
-__global__ __launch_bounds__(THREADS) void pooled_kernel(KParams p) {
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 4) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
   static_assert(!ORD || TAIL != 1, "ORD: no COLD variant");   // (ORD + DONATE: a frame rendered through a pixel list BORROWED from a neighbouring view, round 6)
   static_assert(!CULL || !ALL_LDS, "CULL: instantiated for the general scene path only");
@@ -1766,7 +1771,12 @@ static hipError_t launch_pooled_16(const KParams &p, bool all_lds, int grid, hip
 hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_wg, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
-  if (p.cull && waves_per_wg != 16) return hipErrorInvalidValue;
+  if (p.cull && waves_per_wg != 16 && waves_per_wg != 4) return hipErrorInvalidValue;
+  // (workgroups of four waves, CULL: the plain kernel -- batches and large frames in the shape of five workgroups per CU, api.cpp: make_plan)
+  if (p.cull && waves_per_wg == 4) {
+    if (stats || p.px_hdr != nullptr) return hipErrorInvalidValue;
+    return launch_pooled_t<256, false, false, false, 0, false, true>(p, grid, stream);
+  }
   if (stats && p.px_hdr != nullptr && waves_per_wg == 16)   // (the instrumented launch of a view that renders through its pixel list)
     return p.solo ? launch_pooled_16<true, true, 0, true>(p, all_lds, grid, stream) : launch_pooled_16<true, false, 0, true>(p, all_lds, grid, stream);
   if (stats) return waves_per_wg == 16 ? launch_pooled_16<true, false, 0, false>(p, all_lds, grid, stream) : launch_pooled_t<512, false, true>(p, grid, stream);
@@ -1840,6 +1850,8 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, true, false, false, 2, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false, 0, false, true>);
   // ... and their CULL flavours
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, true, true>);

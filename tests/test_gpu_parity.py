@@ -314,7 +314,8 @@ def test_pixel_tickets(R, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(cull=1), dict(cull=-1), dict(cull=0), dict(cull=1, pixel_order=2, look_max=1, thr_shade=64), dict(cull=1, pixel_order=0, deep_class=8, deep_split=6, deep_cap_log2=0),
-                                  dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8, solo=0), dict(cull=1, lds_scene_bytes=0, gpu_build=0)])
+                                  dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8, solo=0), dict(cull=1, lds_scene_bytes=0, gpu_build=0),
+                                  dict(cull=1, wide_waves=2), dict(cull=0, wide_waves=2, look_max=64, thr_shade=1), dict(cull=-1, waves_per_wg=4, wgs_per_cu=5)])
 def test_cull_by_best_hit(R, opts):
     """The CULL instantiations of the pooled kernel (lane_core.h: cull_limit): boxes are tested against the slot's best
     root so far, widened by a proven margin, instead of the reference's fixed 1e9 (ray.fut:77) -- fewer tests, the SAME fold result
@@ -349,10 +350,16 @@ def test_cull_by_best_hit(R, opts):
             culled = "+CULL" in c.last_launch
             if opts["cull"] == 0 or tall or name == "rgbbox":    # (rgbbox: height 14 > 10 sweeps)
                 assert not culled, (name, c.last_launch)
-            elif opts["cull"] == 1 and "waves=16" in c.last_launch:
+            elif opts["cull"] == 1 and ("waves=16" in c.last_launch or "waves=4" in c.last_launch):
                 assert culled, (name, c.last_launch)
             elif opts["cull"] == -1 and "waves=16" in c.last_launch and "lds_scene_bytes" not in opts:
                 assert culled == (not whole_lds), (name, c.last_launch)
+            # (wide_waves = 2 / the shape configured: five workgroups of four waves per CU for every launch of a scene that is read from L2 and
+            # whose tree is at most 15 levels tall -- irreg's is exactly that; scenes that fit in LDS and taller trees keep 16 waves)
+            if name == "irreg" and (opts.get("wide_waves") == 2 or opts.get("wgs_per_cu") == 5):
+                assert "waves=4" in c.last_launch and ("grid=1280" in c.last_launch or "grid=640" in c.last_launch), c.last_launch
+            if (name == "rgbbox" or tall) and opts.get("wide_waves") == 2:
+                assert "grid=1280" not in c.last_launch and "grid=640" not in c.last_launch, c.last_launch
         rows = R.part_rows(h, 1, 3)
         part = torch.empty((rows, w), dtype=torch.int32, device="cuda")
         for frame in range(3):
@@ -375,7 +382,7 @@ def test_cull_by_best_hit(R, opts):
         R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
         c.sync()
         assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch")
-        if opts["cull"] == 1 and not tall and name != "rgbbox" and "waves=16" in c.last_launch:
+        if opts["cull"] == 1 and not tall and name != "rgbbox" and ("waves=16" in c.last_launch or "waves=4" in c.last_launch):
             assert "+CULL" in c.last_launch, (name, c.last_launch)
         # a batch with its own cameras: the prepared one, one a little off, and one far outside the scene guard (the whole batch then
         # renders un-culled: every origin must pass)
