@@ -186,6 +186,48 @@ def test_culled_pooled_loop_keeps_the_pixels_on_the_cpu(scene, h, w):
     assert int(got[1]["box"]) <= cnt["box_tests"] and int(got[1]["sphere"]) <= cnt["leaf_tests"]
 
 
+def _box_stack_high_water(height, child_inner, passes, shade, look_max, ops, rng):
+    """The pooled loop's box stack as a list of node depths, played by an adversary: `shade()` roots (<= 64) are pushed whenever fewer
+    than look_max (<= 64) items are left, every other operation pops the <= 64 newest items (BOX; BOX2 -- two levels at once -- when at
+    most 32 are left, as the kernel does) and pushes the inner children that `passes()`; a node at depth height - 1 has leaf children."""
+    stack, high = [], 0
+    for _ in range(ops):
+        if len(stack) < look_max and (not stack or rng.random() < 0.5):
+            stack += [0] * shade()
+        elif stack:
+            k = min(64, len(stack))
+            popped, stack = stack[-k:], stack[:-k]
+            levels = 2 if k <= 32 else 1
+            for _ in range(levels):
+                popped = [d + 1 for d in popped for _ in range(2) if d + 1 < height and child_inner() and passes()]
+            stack += popped
+        high = max(high, len(stack))
+    return high
+
+
+@pytest.mark.parametrize("height", [1, 2, 3, 7, 15, 22])
+def test_box_stack_bound_of_the_pooled_loop(height):
+    """the box stack holds at most 64 H + 63 items (H = levels of inner nodes) -- the capacity of the twenty-wave shape,
+    64 (H + 2) dwords, rests on it (api.cpp: make_plan).  The greedy adversary (a complete tree, every box passes, 64 roots whenever the look
+    allows) reaches the bound exactly for H >= 2; random adversaries (ragged trees, partial passes, any look_max) stay below it."""
+    rng = np.random.default_rng(height)
+    bound = 64 * height + 63
+    class Always:                 # (the greedy adversary shades whenever the look allows: 63 roots first, 64 on top of them, 64 from then on)
+        def random(self):
+            return 0.0
+    first = [63]
+    greedy = _box_stack_high_water(height, lambda: True, lambda: True, lambda: first.pop() if first else 64, 64, 40 * height + 200, Always())
+    assert greedy <= max(bound, 127)
+    if height >= 2:
+        assert greedy == bound
+    for trial in range(60):
+        p_inner, p_pass = rng.choice([1.0, 0.95, 0.8, 0.5]), rng.choice([1.0, 0.9, 0.6])
+        look = int(rng.choice([1, 8, 16, 32, 64]))
+        high = _box_stack_high_water(height, lambda: rng.random() < p_inner, lambda: rng.random() < p_pass,
+                                     lambda: int(rng.integers(1, 65)), look, 400, rng)
+        assert high <= max(bound, 127), (trial, p_inner, p_pass, look, high)
+
+
 def test_reference_harness_builds_against_our_header():
     """/root/reference/futhark/main.c must compile and link unmodified (build container only)."""
     if not os.path.exists("/root/reference/futhark/main.c"):
