@@ -75,7 +75,7 @@ const char *rt_last_error(const rt_context *ctx);       /* "" when no error; own
  *   "family=pooled tickets=T instantiation=I[+CULL] frames=.. tiles=.. grid=.. waves=.. counters=..[(turns)] deep_class=.. deep_split=.. recording=0|1|2"
  *     T = pixel-list | tiles-ordered | tiles-bit-reversed (a view's first frame with nothing to borrow, first_order = 1) | tiles-raster,
  *         followed by "(borrowed)" when the order / list is another view's (a new view of a prepared scene that has rendered a view of the same shape)
- *     I = plain | SOLO | COLD | COLD+SOLO | DONATE | DONATE+SOLO | ORD | ORD+SOLO | ORD+DONATE | ORD+SOLO+DONATE;  +CULL: boxes tested against the best hit so far
+ *     I = plain | SOLO | COLD | COLD+SOLO | DONATE | DONATE+SOLO | ORD | ORD+SOLO | ORD+DONATE | ORD+SOLO+DONATE;  +CULL: boxes tested against the best hit so far; +SPILL: a box stack that may overflow into device memory (twenty waves per CU, trees taller than 15 levels)
  *     recording: 0 nothing, 1 the tiles' longest chains, 2 also every pixel's chain length */
 const char *rt_context_last_launch(const rt_context *ctx);
 int rt_context_sync(rt_context *ctx);

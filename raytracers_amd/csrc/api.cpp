@@ -168,6 +168,7 @@ struct Plan {
   int lds_nodes, lds_sph, smax, lmax, waves, grid;
   int grid_full;   // every persistent workgroup (grid == grid_full unless grid_div says otherwise)
   int capb, capl, ray_planes;
+  int spill_stride;   // > 0: capb is below the box stack's bound -- the launch needs a spill region of this many dwords per wave (the twenty-wave shape, tall trees)
   size_t lds_bytes;
 };
 
@@ -200,7 +201,10 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   // pushed behind it have strictly increasing minimum depths 1 .. H - 1, every block but the top one holds at most 64 items, the top one at
   // most 128: 63 + 64 (H - 2) + 128 = 64 H + 63 items)
   struct Shape { int wgs, waves, planes; };
-  auto capb_of = [&](const Shape &sh) { return 64 * (ps->height + (sh.wgs * sh.waves == 20 ? 2 : 3)); };
+  // (... capped at what a twentieth of the LDS leaves a wave -- 2 000 - 196 - 512 - 192 dwords -- for taller trees: the kernels of that shape keep the oldest items
+  // of a stack that would overflow in device memory, render_kernels.hip: SPILL)
+  const int cap20 = ctx->stack_cap ? rtk::kSpillCapbTest : rtk::kSpillCapb;
+  auto capb_of = [&](const Shape &sh) { return sh.wgs * sh.waves == 20 ? std::min(64 * (ps->height + 2), cap20) : 64 * (ps->height + 3); };
   pl->capb = 64 * (ps->height + 3);
   pl->capl = 192;
   // Workgroup shape {workgroups per CU, waves per workgroup}.  The per-wave scratch grows with the
@@ -261,6 +265,7 @@ int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, 
   pl->waves = shapes[static_cast<size_t>(pick)].waves;
   pl->ray_planes = shapes[static_cast<size_t>(pick)].planes;
   pl->capb = capb_of(shapes[static_cast<size_t>(pick)]);
+  pl->spill_stride = (wgs * pl->waves == 20 && pl->capb < 64 * (ps->height + 2)) ? 64 * (ps->height + 2) : 0;
   int budget = budget_of(shapes[static_cast<size_t>(pick)]);
   if (ctx->lds_scene_bytes >= 0) budget = std::min(budget, ctx->lds_scene_bytes);
   int ln, ls;
@@ -483,6 +488,9 @@ void drain_streams(rt_context *ctx) {
   if (ctx->sort_stream_px) (void)hipStreamSynchronize(ctx->sort_stream_px);
 }
 
+// Is the traversal copy of the scene (64 bytes per inner node, 16 per sphere) larger than the eight L2s together?
+bool rt_scene_exceeds_l2(const rt_prepared *ps) { return static_cast<int64_t>(ps->n) * 80 > (int64_t(32) << 20); }
+
 // May this launch cull (lane_core.h: cull_limit)?  The scene's guards (rt_prepared::cull), the launch shape the CULL instantiations
 // exist for, and every camera origin of the launch inside the scene guard -- a batch's cameras are read from the context's pinned
 // copy of them (stage_cams); cameras that live only on the device switch culling off.
@@ -577,7 +585,11 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
     // (twenty waves per CU: batches and frames of 100 000 tiles or more -- launches bound by their work.  Measured, profiles/r06/exp/e11: irreg's batch of 20
     // frames of 1000 x 1000 0.110 -> 0.104 ms per frame, one frame of 4000 x 4000 1.72 -> 1.63 ms, 2000 x 2000 -- 62 500 tiles -- the same; single frames
     // within the pixel list's range keep the 16-wave kernels, whose ORD / SOLO / DONATE instantiations they are rendered by)
-    const bool wide = ctx->wide_waves == 2 || (ctx->wide_waves == 1 && ntiles1 * nframes >= 100000 && (nframes > 1 || ntiles1 > ctx->px_max_tiles));
+    // (a scene larger than the chip's L2s -- 32 MB; the 10^6-sphere scene is 80 -- takes the shape from every frame beyond the pixel list's range, together with a
+    // ticket counter per XCD over its own STRIP of the image, below: 2000 x 2000 1.01 -> 0.925 ms, 4000 x 4000 2.47 -> 2.30; e13.  Trees taller than 15 levels run
+    // the SPILL kernels in that shape)
+    const bool huge = rt_scene_exceeds_l2(ps);
+    const bool wide = ctx->wide_waves == 2 || (ctx->wide_waves == 1 && ntiles1 * nframes >= (huge ? 40000 : 100000) && (nframes > 1 || ntiles1 > ctx->px_max_tiles));
     if (int rc = make_plan(ctx, ps, &pl, ntiles1 * nframes, 0, wide)) return rc;
   }
   tick("plan");
@@ -622,7 +634,9 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   // the 10^6-sphere frame's L2 hit rate 65.9 -> 66.9 %; slower than taking turns because the deepest tiles -- the ones
   // handed out in pieces -- are not spread evenly over the strips); single frames only: a batch's class-major ticket
   // order is defined over one queue.
-  const int xq = ctx->xcd_queues < 0 ? 2 : ctx->xcd_queues;
+  // (... except for one frame of a scene larger than the L2s in the twenty-wave shape: there the strips win -- an XCD's L2 then serves the part of the scene its
+  // strip of the image looks at; 10^6 spheres at 2000 x 2000: 0.99-1.05 ms taking turns, 0.925 in strips; with 16 waves per CU 1.01 / 1.00)
+  const int xq = ctx->xcd_queues < 0 ? ((nframes == 1 && pl.variant == RT_VARIANT_POOLED && pl.waves * (pl.grid_full / std::max(1, ctx->num_cu)) == 20 && rt_scene_exceeds_l2(ps)) ? 1 : 2) : ctx->xcd_queues;
   p.nshards = (xq && (nframes == 1 || xq == 2) && pl.variant == RT_VARIANT_POOLED && pl.grid % rtk::kMaxShards == 0) ? rtk::kMaxShards : 1;
   p.interleave = p.nshards > 1 && xq == 2;
   const int order_shards = p.interleave ? 1 : p.nshards;   // layout of the view's order table
@@ -631,6 +645,19 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.smax = pl.smax; p.lmax = pl.lmax;
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
+  if (pl.spill_stride > 0) {
+    // (the overflow regions of the waves' box stacks: allocated by the first launch that needs them -- a tall tree in the twenty-wave shape)
+    const size_t need = sizeof(unsigned) * static_cast<size_t>(pl.spill_stride) * static_cast<size_t>(pl.grid_full) * static_cast<size_t>(pl.waves);
+    if (ctx->spill_bytes < need) {
+      drain_streams(ctx);
+      if (ctx->spill_dev) (void)hipFree(ctx->spill_dev);
+      ctx->spill_dev = nullptr; ctx->spill_bytes = 0;
+      RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->spill_dev), need));
+      ctx->spill_bytes = need;
+    }
+    p.spill = ctx->spill_dev;
+    p.spill_stride = pl.spill_stride;
+  }
   p.prio_depth = ctx->prio_depth;
   p.box2 = ctx->box2;
   // (batches, and launches of more than 16 384 tiles -- frames beyond 1000 x 1000 and a rank's share of a 4000 x 4000 one: -1.8 .. -3.6 %
@@ -851,8 +878,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
       const char *inst = p.px_hdr ? (p.donate ? (p.solo ? "ORD+SOLO+DONATE" : "ORD+DONATE") : (p.solo ? "ORD+SOLO" : "ORD")) : (p.cold && pl.waves == 16) ? (single_px ? "COLD+SOLO" : "COLD")
                          : (p.donate && pl.waves == 16) ? (single_px ? "DONATE+SOLO" : "DONATE") : (single_px ? "SOLO" : "plain");
       char buf[256];
-      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s%s instantiation=%s%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
-                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), borrowed ? "(borrowed)" : "", inst, p.cull ? "+CULL" : "", p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
+      std::snprintf(buf, sizeof buf, "family=pooled tickets=%s%s instantiation=%s%s%s frames=%d tiles=%d grid=%d waves=%d counters=%d%s deep_class=%d deep_split=%d recording=%d",
+                    p.px_hdr ? "pixel-list" : first_order ? "tiles-bit-reversed" : (p.order ? "tiles-ordered" : "tiles-raster"), borrowed ? "(borrowed)" : "", inst, p.cull ? "+CULL" : "", p.spill ? "+SPILL" : "", p.nframes, p.nchunks, pl.grid, pl.waves, p.nshards,
                     p.interleave ? "(turns)" : "", p.px_hdr ? 0 : p.deep_class, p.px_hdr ? 0 : p.deep_split, p.cost ? (p.cost_px ? 2 : 1) : 0);
       ctx->last_launch = buf;
     }
@@ -964,6 +991,7 @@ extern "C" void rt_context_destroy(rt_context *ctx) {
   if (ctx->cams_host) (void)hipHostFree(ctx->cams_host);
   if (ctx->cams_event) (void)hipEventDestroy(ctx->cams_event);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
+  if (ctx->spill_dev) (void)hipFree(ctx->spill_dev);
   if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
   if (ctx->px_scratch) (void)hipFree(ctx->px_scratch);
   if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
@@ -1119,6 +1147,9 @@ extern "C" int rt_context_set_option(rt_context *ctx, const char *name, int64_t 
     ctx->eager_sort = v != 0;
   } else if (k == "borrow") {
     ctx->borrow = std::max(0, std::min(4, v));
+  } else if (k == "stack_cap") {
+    if (v != 0 && v != rtk::kSpillCapbTest) return fail(ctx, "stack_cap must be 0 or 192");
+    ctx->stack_cap = v;
   } else if (k == "wide_waves") {
     ctx->wide_waves = std::max(0, std::min(2, v));
   } else if (k == "cull") {

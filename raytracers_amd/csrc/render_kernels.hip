@@ -604,7 +604,10 @@ __device__ __attribute__((noinline)) void solo_trace(KParamsArg pp_v, unsigned s
 // allocator stay within the 96 VGPRs five waves per SIMD leave each (the 16-wave kernels hold 99-101; the difference is one dword spilled
 // in SHADE).  (Two workgroups of ten waves do not do it: a workgroup's waves go to the SIMDs round robin from SIMD 0, ten waves are 3 3 2 2,
 // and a second workgroup would need six wave slots of 96 VGPRs on SIMD 0 -- it never becomes resident: measured, profiles/r06/exp/e11.)
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false>
+// SPILL: the instantiation of that shape for trees TALLER than 15 levels, whose box stacks may outgrow the LDS a twentieth of a CU leaves them (below); its
+// value is the stack size beyond which a full BOX operation spills first -- a literal: p.capb - 64 with p.capb = 1 088 (production) or 192 (stack_cap, testing);
+// compared with p.capb itself the check was a scalar load and its wait in every BOX operation of a well-filled stack: the 10^6-sphere frame 7 % slower.
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO, int TAIL = 0, bool ORD = false, bool CULL = false, int SPILL = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 4) void pooled_kernel(KParams p) {
   constexpr bool COLD = TAIL == 1, DONATE = TAIL == 2;
   static_assert(!ORD || TAIL != 1, "ORD: no COLD variant");   // (ORD + DONATE: a frame rendered through a pixel list BORROWED from a neighbouring view, round 6)
@@ -649,6 +652,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 
   unsigned long long n_rays = 0, n_box = 0, n_sph = 0;
   // ---- wave state (uniform) ----
   int nbox = 0, nleaf = 0;
+  // SPILL (four-wave workgroups in the shape of twenty waves per CU, tall trees): p.capb is smaller than the stack's bound (trees taller than 15 levels do not
+  // leave a wave 64 H + 63 dwords there).  A full BOX operation that could push beyond it first moves the OLDEST half of the stack -- its bottom -- to the wave's
+  // region of p.spill; the newest spilled chunk comes back when the LDS stack has run empty; no SHADE while anything is spilled.  The order of the operations is
+  // that of the unbounded LIFO (its bottom is what it would reach last anyway), so the bound on LDS + memory together is the proven 64 H + 63.  Scenes met so
+  // far stay far below their capacity (high-water marks 437 .. 588 items, tools/trace_waves.py): the path is the guarantee, not the rule.
+  static_assert(!SPILL || (THREADS == 256 && !ALL_LDS && !SOLO && TAIL == 0 && !ORD), "SPILL: the plain and CULL kernels of the four-wave workgroups");
+  // (the number of spilled items lives in the wave's second dump dword, the region's base is recomputed where it is needed: the loop has no scalar register to
+  // spare -- with both kept in registers the kernel ran 4-5 % slower whether or not anything spilled, profiles/r06/exp/e13)
+  unsigned *const wspill = wbase + 193;
+  auto spill_region = [&]() { return p.spill + (size_t)(blockIdx.x * (THREADS / 64) + wave) * (size_t)p.spill_stride; };
   unsigned q_next = 0, q_end = 0;
   int q_tile = 0;          // tile the current ticket maps to
   int q_col0 = 0, q_row0 = 0;   // its first pixel column / local row
@@ -776,6 +789,20 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 
   for (;;) {
     RT_MARK("CHOICE_BEGIN");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (SPILL) {
+      if (nbox == 0) {
+        const int nspill = uni((int)*wspill);
+        if (__builtin_expect(nspill != 0, 0)) {      // the LDS stack ran empty: the newest spilled chunk comes back
+          const int n = nspill < 128 ? nspill : 128;
+          const unsigned *const src = spill_region() + (nspill - n);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          for (int i = lane; i < n; i += 64) wbox[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) *wspill = (unsigned)(nspill - n);
+          nbox = uni(n);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+      }
+    }
     // (both counters are wave-uniform by construction -- ballot popcounts -- and every update goes
     // through uni(): hipcc's divergence analysis otherwise carries them in VGPRs and predicates
     // the phases)
@@ -802,7 +829,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 
      // (... and not while the box stack still holds look_max items or more: there is box work for at least half a wave, the
      // folds that are finished can wait one more operation, and the look's LDS round trip is saved -- 1-2.5 % in the throughput
      // regimes, profiles/r04/exp/e10; a single frame of <= 32 768 tiles looks whenever fewer than 64 items are left, as before)
-     if (nbox == 0 || (nbox < p.look_max && (int)__popcll(m_live | bal(vacant)) >= thr)) {
+     // (SPILL: no SHADE while a part of the stack is in memory -- the bound on the stack rests on a SHADE finding at most 63 items)
+     const bool spilled = SPILL && uni((int)*wspill) != 0;
+     if (nbox == 0 || (!spilled && nbox < p.look_max && (int)__popcll(m_live | bal(vacant)) >= thr)) {
       // With leaf items pending `done` over-estimates (the counter covers inner-node items only): it
       // then only decides whether to drain the leaf list now.
       const bool done = (pix >= 0) & (wcnt[lane] == 0);
@@ -1274,6 +1303,23 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 5 : (THREADS / 64 + 3) / 
       };
       const unsigned long long tr_b0 = STATS ? clock64() : 0ull;
       int tr_kind = 0;
+      if constexpr (SPILL) {
+        if (__builtin_expect(nbox > SPILL, 0)) {                        // a full batch may push 128 behind its 64: the oldest half of the stack goes to memory
+          const int S = (nbox >> 1) & ~63;                               // (whole chunks, at least one)
+          const int nspill = uni((int)*wspill);
+          unsigned *const dst = spill_region() + nspill;
+          for (int i = lane; i < S; i += 64) __hip_atomic_store(&dst[i], wbox[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int i = lane; i < nbox - S; i += 64) {                    // the rest moves down (a wave's LDS operations execute in order)
+            const unsigned v = wbox[S + i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            wbox[i] = v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (lane == 0) *wspill = (unsigned)(nspill + S);
+          nbox = uni(nbox - S);
+        }
+      }
       if (nbox >= 64) box(std::true_type{});
       else if (nbox <= 32 && p.box2) { box2(); tr_kind = 1; }
       else box(std::false_type{});
@@ -1747,10 +1793,10 @@ size_t pooled_lds_bytes(int lds_nodes, int lds_sph, int capb, int capl, int ray_
   return (size_t)lds_nodes * 64 + (size_t)lds_sph * 16 + (size_t)waves_per_wg * pooled_wave_dw(ray_planes, capb, capl) * sizeof(unsigned);
 }
 
-template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0, bool ORD = false, bool CULL = false>
+template <int THREADS, bool ALL_LDS, bool STATS, bool SOLO = false, int TAIL = 0, bool ORD = false, bool CULL = false, int SPILL = 0>
 static hipError_t launch_pooled_t(const KParams &p, int grid, hipStream_t stream) {
   const size_t lds = pooled_lds_bytes(p.lds_nodes, p.lds_sph, p.capb, p.capl, p.ray_planes, THREADS / 64);
-  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL, ORD, CULL>;
+  auto kfn = pooled_kernel<THREADS, ALL_LDS, STATS, SOLO, TAIL, ORD, CULL, SPILL>;
   if (hipError_t e = allow_full_lds(reinterpret_cast<const void *>(kfn)); e != hipSuccess) return e;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, stream, p);
   return hipGetLastError();
@@ -1772,7 +1818,14 @@ hipError_t launch_pooled(const KParams &p, bool stats, int grid, int waves_per_w
   if (grid <= 0) return hipSuccess;
   const bool all_lds = p.lds_nodes == p.n_nodes && p.lds_sph == p.n_sph;
   if (p.cull && waves_per_wg != 16 && waves_per_wg != 4) return hipErrorInvalidValue;
-  // (workgroups of four waves, CULL: the plain kernel -- batches and large frames in the shape of five workgroups per CU, api.cpp: make_plan)
+  // (workgroups of four waves, CULL: the plain kernel -- batches and large frames in the shape of five workgroups per CU, api.cpp: make_plan;
+  // p.spill: that shape for a tree taller than 15 levels -- the kernels whose box stack may overflow into device memory)
+  if (p.spill != nullptr) {
+    if (waves_per_wg != 4 || stats || p.px_hdr != nullptr || (p.capb != kSpillCapb && p.capb != kSpillCapbTest)) return hipErrorInvalidValue;
+    if (p.capb == kSpillCapbTest)
+      return p.cull ? launch_pooled_t<256, false, false, false, 0, false, true, kSpillCapbTest - 64>(p, grid, stream) : launch_pooled_t<256, false, false, false, 0, false, false, kSpillCapbTest - 64>(p, grid, stream);
+    return p.cull ? launch_pooled_t<256, false, false, false, 0, false, true, kSpillCapb - 64>(p, grid, stream) : launch_pooled_t<256, false, false, false, 0, false, false, kSpillCapb - 64>(p, grid, stream);
+  }
   if (p.cull && waves_per_wg == 4) {
     if (stats || p.px_hdr != nullptr) return hipErrorInvalidValue;
     return launch_pooled_t<256, false, false, false, 0, false, true>(p, grid, stream);
@@ -1852,6 +1905,8 @@ void warm_render_kernels() {
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false, 0, false, true>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false, 0, false, false, kSpillCapb - 64>);
+  (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<256, false, false, false, 0, false, true, kSpillCapb - 64>);
   // ... and their CULL flavours
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, false, 2, true, true>);
   (void)hipFuncGetAttributes(&a, (const void *)pooled_kernel<1024, false, false, true, 2, true, true>);

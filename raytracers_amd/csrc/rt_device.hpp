@@ -13,6 +13,9 @@ constexpr int kStackPixel = 64;   // pixel_kernel: LDS stack entries per lane (>
 // table (ray_planes x 64 float4), the box stack and the leaf list
 constexpr int kPooledWaveFixedDw = 128 + 64 + 4;
 constexpr int pooled_wave_dw(int ray_planes, int capb, int capl) { return kPooledWaveFixedDw + 256 * ray_planes + capb + capl; }
+// the shape of twenty waves per CU: the LDS box stack a wave can have there (2 000 - 196 - 512 - 192 dwords, whole batches), and the tiny one that
+// option stack_cap selects to make the SPILL kernels spill all the time (testing)
+constexpr int kSpillCapb = 1088, kSpillCapbTest = 192;
 
 // ---- the tile queue of the persistent families --------------------------------------------------
 // Tickets are drawn with returning device-scope atomics; one word saturates at ~88 draws per microsecond
@@ -259,6 +262,10 @@ struct KParams {
   float cull_kappa;      // ... and in the limit best + W2 (best^2 + kappa)   (api.cpp: the prepared scene's CullConst)
   const float *u_tab;    // [w]  pixel_u(col, w)
   const float *v_tab;    // [h]  pixel_v(row, h), indexed by the FULL image row
+  // pooled family, workgroups of four waves (the shape of twenty waves per CU): a box stack whose LDS capacity `capb` is BELOW its bound (64 H + 63: trees taller
+  // than 15 levels) keeps its oldest items in device memory when it would overflow -- [waves][spill_stride] dwords, a wave's own region (nullptr: capb holds the bound)
+  unsigned *spill;
+  int spill_stride;
 };
 
 hipError_t launch_pixel(const KParams &p, bool stats, hipStream_t stream);

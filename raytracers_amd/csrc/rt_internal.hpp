@@ -70,6 +70,7 @@ struct rt_context {
   int px_zip = 1;           // ... the bulk's tickets alternately from the long and from the short end of its segment (0: sorted straight through)
   int px_prio = 3;          // ... at this issue priority (s_setprio 0 .. 3)
   int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
+  int stack_cap = 0;        // testing: caps the LDS box stack of the twenty-wave shape (192 dwords; 0: as large as fits) -- a small cap makes the spill path run all the time
   int wide_waves = 1;       // pooled family: five workgroups of four waves per CU (five waves per SIMD) for scenes read from L2 -- 1 (default): launches of 100 000 tiles or more (batches; frames beyond the pixel list's range), trees of height <= 15; 2: every launch (testing); 0: never
   int cull = -1;            // pooled family, workgroups of 16 waves: the CULL instantiations -- boxes tested against the slot's best root so far (lane_core.h: cull_limit; same pixels, fewer tests).  -1 (auto): where the scene and the camera pass the proof's guards (rt_host.hpp: CullConst) and the scene is not wholly LDS resident (rgbbox-sized scenes: the walk is short, the tests saved do not pay for the limit's three instructions per item); 1: wherever the guards pass; 0: never
   int eager_sort = 1;       // pooled family: 1 = the sorts that turn a view's record into its tile order and pixel list are launched right behind the recording frame on the context's SECOND stream (they run while the caller synchronises / sets up its next call; the view's next frame -- or a new view that borrows the order -- waits for their event, usually long past); 0 = lazily on the main stream, ahead of the view's next frame (round 5)
@@ -80,6 +81,8 @@ struct rt_context {
   hipStream_t sort_stream = nullptr, sort_stream_px = nullptr;   // the sort streams (eager_sort): a recorded view's tile order; its pixel list
   hipEvent_t rec_event = nullptr;      // main stream -> sort stream: "the recording frame has been enqueued up to here"
   unsigned *queue_dev = nullptr;
+  unsigned *spill_dev = nullptr;   // pooled family, twenty waves per CU, trees taller than 15 levels: the waves' box-stack overflow regions (rt_device.hpp: KParams::spill); allocated by the first launch that needs it
+  size_t spill_bytes = 0;
   int *order_scratch = nullptr;   // the tile-order sort's chunk counts (rtk::kOrderScratchInts), allocated with the first record
   int *px_scratch = nullptr;      // the pixel-list sort's counts (rtk::px_scratch_ints()), likewise
   unsigned long long *stats_dev = nullptr;

@@ -313,6 +313,55 @@ def test_pixel_tickets(R, opts):
     c.close()
 
 
+@pytest.mark.parametrize("opts", [dict(stack_cap=192), dict(stack_cap=192, cull=0, look_max=64, thr_shade=1), dict(stack_cap=192, box2=0, cull=1), dict(stack_cap=192, waves_per_wg=4, wgs_per_cu=5),
+                                  dict(stack_cap=0)])
+def test_box_stack_spills_to_memory(R, opts):
+    """The shape of twenty waves per CU caps a wave's LDS box stack at 1 088 dwords; trees taller than 15 levels have a larger bound (64 H + 63), and
+    the four-wave kernels then keep the oldest half of a stack that would overflow in device memory (render_kernels.hip: SPILL; KParams::spill) and
+    fetch it back when the LDS part has run empty.  stack_cap forces tiny capacities, so the path runs thousands of times per frame: single
+    frames of a view (recording, ordered), a part, a batch -- the reference scenes, 90 000 spheres, a 36-level tree -- all bit-exact."""
+    import torch
+    from raytracers_amd.dist import tile_rows
+    c = R.Context()
+    c.set_variant(3)
+    c.set_option("wide_waves", 2)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    cases = [cs for cs in _solo_cases() if cs[0] != "floor:37:222"] + [("irreg", None, 500, 500)]
+    for name, custom, h, w in cases:
+        if custom is None:
+            orc, sc = _oracle(name), _scene(c, name)
+        else:
+            orc = O.OracleScene("custom", spheres7=custom[0], look_from=custom[1], look_at=custom[2], fov=custom[3])
+            sc = c.scene_from_spheres(*custom)
+        want, _ = orc.render(h, w)
+        ps = R.prepare_scene(h, w, sc)
+        out = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        for frame in range(3):
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            R.render_into(out.data_ptr(), h, w, ps)
+            c.sync()
+            assert int((out.cpu().numpy() != want).sum()) == 0, (name, frame, c.last_launch)
+            if name in ("irreg", "floor:300:1800"):
+                assert "waves=4" in c.last_launch, (name, c.last_launch)     # (scenes read from L2, whatever their height: the twenty-wave shape)
+                # (irreg's 15 levels fit the LDS stack unless stack_cap says otherwise; 90 000 spheres are taller)
+                assert ("+SPILL" in c.last_launch) == (opts["stack_cap"] != 0 or name == "floor:300:1800"), (name, c.last_launch)
+        rows = R.part_rows(h, 1, 3)
+        part = torch.full((rows, w), -3, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_into(part.data_ptr(), h, w, ps, part=1, nparts=3)
+        c.sync()
+        assert int((part.cpu().numpy() != want[tile_rows(h, 1, 3)]).sum()) == 0, (name, "part")
+        buf = torch.full((3, h, w), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        R.render_batch_into(buf.data_ptr(), h, w, ps, 3, frame_stride=h * w)
+        c.sync()
+        assert all(int((f != want).sum()) == 0 for f in buf.cpu().numpy()), (name, "batch", c.last_launch)
+        ps.free()
+    c.close()
+
+
 @pytest.mark.parametrize("opts", [dict(cull=1), dict(cull=-1), dict(cull=0), dict(cull=1, pixel_order=2, look_max=1, thr_shade=64), dict(cull=1, pixel_order=0, deep_class=8, deep_split=6, deep_cap_log2=0),
                                   dict(cull=1, handover=2, donate_max=8), dict(cull=1, box2=0, thr_shade=8, solo=0), dict(cull=1, lds_scene_bytes=0, gpu_build=0),
                                   dict(cull=1, wide_waves=2), dict(cull=0, wide_waves=2, look_max=64, thr_shade=1), dict(cull=-1, waves_per_wg=4, wgs_per_cu=5)])
