@@ -228,6 +228,49 @@ def test_box_stack_bound_of_the_pooled_loop(height):
         assert high <= max(bound, 127), (trial, p_inner, p_pass, look, high)
 
 
+@pytest.mark.parametrize("height,cap", [(7, 192), (19, 192), (19, 1088), (30, 1088), (40, 448)])
+def test_spilling_box_stack_discipline(height, cap):
+    """The SPILL kernels' bookkeeping (render_kernels.hip) as a model: an LDS stack of `cap` dwords, the oldest half (whole
+    batches of 64) moved to memory before a full BOX operation that finds more than cap - 64 items, the newest spilled chunk (<= 128) fetched
+    back when the LDS part is empty, no SHADE while anything is spilled.  Against a greedy adversary (complete tree, every box passes) and
+    random ones: the LDS part never exceeds its capacity, LDS + memory never exceed the LIFO's bound 64 H + 63, nothing is lost."""
+    bound = max(64 * height + 63, 127)
+    for trial in range(12):
+        rng = np.random.default_rng(1000 * height + trial)
+        p_inner, p_pass = (1.0, 1.0) if trial == 0 else (rng.choice([1.0, 0.97, 0.9]), rng.choice([1.0, 0.95, 0.8]))
+        lds, mem, pushed, popped, high_all, budget = [], [], 0, 0, 0, 40 * height + 400
+        while budget > 0 or lds or mem:
+            draining = budget <= 0                                # (the adversary's time is up: no more rays, no box passes -- the stack drains)
+            if not lds and mem:                                   # loop top: the newest chunk comes back
+                n = min(len(mem), 128)
+                lds, mem = mem[-n:], mem[:-n]
+            if not draining and not mem and len(lds) < 64 and (not lds or rng.random() < 0.5):   # SHADE (look_max = 64)
+                k = 63 if pushed == 0 else (int(rng.integers(1, 65)) if trial else 64)
+                lds += [0] * k
+                pushed += k
+            elif lds:
+                if len(lds) >= 64 and len(lds) > cap - 64:        # a full batch may push 128 behind its 64
+                    S = (len(lds) >> 1) & ~63
+                    assert S >= 64
+                    mem += lds[:S]
+                    lds = lds[S:]
+                k = min(64, len(lds))
+                items, lds = lds[-k:], lds[:-k]
+                popped += k
+                for _ in range(2 if k <= 32 else 1):               # BOX2: two levels at once (the level between never reaches the stack)
+                    items = [d + 1 for d in items for _ in range(2)
+                             if not draining and d + 1 < height and rng.random() < p_inner and rng.random() < p_pass]
+                lds += items
+                pushed += len(items)
+            budget -= 1
+            high_all = max(high_all, len(lds) + len(mem))
+            assert len(lds) <= cap, (trial, len(lds))
+        assert high_all <= bound, (trial, high_all, bound)
+        assert pushed == popped, (trial, pushed, popped)          # every item left the stack exactly once
+        if trial == 0 and cap < 64 * height:
+            assert high_all > cap                                  # (the greedy adversary does make it spill)
+
+
 def test_reference_harness_builds_against_our_header():
     """/root/reference/futhark/main.c must compile and link unmodified (build container only)."""
     if not os.path.exists("/root/reference/futhark/main.c"):

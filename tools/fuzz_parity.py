@@ -56,7 +56,7 @@ while time.time() < t_end:
     # random launch knobs (must never change pixels)
     knobs = dict(grid_div=int(rng.choice([0, 1, 2, 4, 8, 16])), thr_shade=int(rng.choice([1, 8, 24, 48, 64])),
                  deep_class=int(rng.integers(-1, 9)), adaptive_order=int(rng.choice([0, 1, 1, 2])),
-                 lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])), wide_waves=int(rng.choice([0, 1, 2])),
+                 lds_scene_bytes=int(rng.choice([-1, -1, 0, 2048, 20000])), waves_per_wg=int(rng.choice([0, 0, 4, 8, 12, 16])), wide_waves=int(rng.choice([0, 1, 2])), stack_cap=int(rng.choice([0, 0, 192])),
                  wgs_per_cu=int(rng.choice([1, 2, 4, 5])), ray_planes=int(rng.choice([0, 2, 3])), box2=int(rng.choice([0, 1, 1])),
                  deep_split=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 6, 6])), deep_cap_log2=int(rng.integers(0, 6)), solo=int(rng.choice([0, 1, 1, 1])),
                  # the tile queue: one counter / a strip of tile columns per counter / counters taking turns, tiles per ticket,
