@@ -177,7 +177,7 @@ struct Plan {
 // half-size launch keeps the waves better filled -- 5-18 % per frame --, larger frames want every wave).
 // `force_waves` != 0: only workgroups of that many waves (the instrumented instantiation has 8).
 // `wide`: the launch may take the shape of FIVE workgroups of four waves per CU (a batch, or a frame too large for a pixel list): five waves
-// per SIMD for scenes that are read from L2 (the plain and CULL kernels only; trees of height <= 15: a wave's region must fit a twentieth of the LDS).
+// per SIMD for scenes that are read from L2 (the plain and CULL kernels only; a wave's region must fit a twentieth of the LDS: trees taller than 15 levels get a box stack that may spill to device memory, Plan::spill_stride).
 int make_plan(rt_context *ctx, const rt_prepared *ps, Plan *pl, int64_t ntiles, int force_waves = 0, bool wide = false) {
   const bool auto_variant = ctx->variant == RT_VARIANT_AUTO;
   pl->variant = ctx->variant;

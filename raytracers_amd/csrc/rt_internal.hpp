@@ -71,7 +71,7 @@ struct rt_context {
   int px_prio = 3;          // ... at this issue priority (s_setprio 0 .. 3)
   int px_solo_div = 4;      // ... at most (waves / this) one-pixel tickets
   int stack_cap = 0;        // testing: caps the LDS box stack of the twenty-wave shape (192 dwords; 0: as large as fits) -- a small cap makes the spill path run all the time
-  int wide_waves = 1;       // pooled family: five workgroups of four waves per CU (five waves per SIMD) for scenes read from L2 -- 1 (default): launches of 100 000 tiles or more (batches; frames beyond the pixel list's range), trees of height <= 15; 2: every launch (testing); 0: never
+  int wide_waves = 1;       // pooled family: five workgroups of four waves per CU (five waves per SIMD) for scenes read from L2 -- 1 (default): launches of 100 000 tiles or more (batches; frames beyond the pixel list's range; from 40 000 tiles for scenes larger than the L2s); 2: every launch (testing); 0: never
   int cull = -1;            // pooled family, workgroups of 16 waves: the CULL instantiations -- boxes tested against the slot's best root so far (lane_core.h: cull_limit; same pixels, fewer tests).  -1 (auto): where the scene and the camera pass the proof's guards (rt_host.hpp: CullConst) and the scene is not wholly LDS resident (rgbbox-sized scenes: the walk is short, the tests saved do not pay for the limit's three instructions per item); 1: wherever the guards pass; 0: never
   int eager_sort = 1;       // pooled family: 1 = the sorts that turn a view's record into its tile order and pixel list are launched right behind the recording frame on the context's SECOND stream (they run while the caller synchronises / sets up its next call; the view's next frame -- or a new view that borrows the order -- waits for their event, usually long past); 0 = lazily on the main stream, ahead of the view's next frame (round 5)
   int borrow = 1;           // pooled family: a NEW view (same image size, partition and bounce limit as a view of this prepared scene already rendered, another camera) renders its first frame through that view's order / pixel list while it records its own -- the order of independent pixels never changes them; the mispredicted long chains are what the DONATE tail is for.  0: a new view's first frame is unordered; 1 (auto): scenes read from L2 only, through the other view's pixel list (a scene that lives in LDS renders its new views unordered: measured as fast); 2: the tile order, 3: the pixel list, for either kind of scene; 4: the pixel list without its holds (testing)
