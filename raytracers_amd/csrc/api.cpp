@@ -490,6 +490,19 @@ void drain_streams(rt_context *ctx) {
   if (ctx->sort_stream_px) (void)hipStreamSynchronize(ctx->sort_stream_px);
 }
 
+// The overflow regions of the waves' box stacks (KParams::spill): `stride` dwords for each wave of the twenty-wave shape.  Allocated by rt_prepare_scene for a tree
+// taller than 15 levels (a synchronisation point anyway) -- or, failing that (options changed since), by the first launch that needs them.
+int ensure_spill(rt_context *ctx, int stride) {
+  const size_t need = sizeof(unsigned) * static_cast<size_t>(stride) * static_cast<size_t>(std::max(1, ctx->num_cu)) * 20;
+  if (ctx->spill_bytes >= need) return 0;
+  drain_streams(ctx);
+  if (ctx->spill_dev) (void)hipFree(ctx->spill_dev);
+  ctx->spill_dev = nullptr; ctx->spill_bytes = 0;
+  RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->spill_dev), need));
+  ctx->spill_bytes = need;
+  return 0;
+}
+
 // Is the traversal copy of the scene (64 bytes per inner node, 16 per sphere) larger than the eight L2s together?
 bool rt_scene_exceeds_l2(const rt_prepared *ps) { return static_cast<int64_t>(ps->n) * 80 > (int64_t(32) << 20); }
 
@@ -648,15 +661,8 @@ int rti::enqueue_render(rt_context *ctx, const rt_prepared *ps, int64_t h, int64
   p.thr_shade = ctx->thr_shade; p.thr_leaf = ctx->thr_leaf;
   p.capb = pl.capb; p.capl = pl.capl; p.ray_planes = pl.ray_planes;
   if (pl.spill_stride > 0) {
-    // (the overflow regions of the waves' box stacks: allocated by the first launch that needs them -- a tall tree in the twenty-wave shape)
-    const size_t need = sizeof(unsigned) * static_cast<size_t>(pl.spill_stride) * static_cast<size_t>(pl.grid_full) * static_cast<size_t>(pl.waves);
-    if (ctx->spill_bytes < need) {
-      drain_streams(ctx);
-      if (ctx->spill_dev) (void)hipFree(ctx->spill_dev);
-      ctx->spill_dev = nullptr; ctx->spill_bytes = 0;
-      RT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->spill_dev), need));
-      ctx->spill_bytes = need;
-    }
+    // (the overflow regions of the waves' box stacks: there since rt_prepare_scene for a tall tree; a no-op then)
+    if (int rc = ensure_spill(ctx, pl.spill_stride)) return rc;
     p.spill = ctx->spill_dev;
     p.spill_stride = pl.spill_stride;
   }
@@ -1344,6 +1350,8 @@ extern "C" int rt_prepare_scene(rt_context *ctx, rt_prepared **out, int64_t h, i
     ps->cull = scene->cull;
     ps->cull.ok = ps->cull.ok && ps->height <= static_cast<int>(log2f(static_cast<float>(n))) + 2;   // every box contains its subtree (bvh.fut:47)
   }
+  // (a tree taller than 15 levels: the twenty-wave shape's box stacks may spill -- their regions are allocated here, not inside a render call)
+  if (!rc && e == hipSuccess && ctx->wide_waves != 0 && ps->height > 15 && n < (int64_t(1) << 22)) rc = ensure_spill(ctx, 64 * (ps->height + 2));
   const int grc = ctx->group ? rti::group_prepare_end(ctx, ps.get()) : 0;   // (joins the replica builds whatever happened here)
   if (rc || e != hipSuccess) {
     rt_prepared_free(ctx, ps.release());
