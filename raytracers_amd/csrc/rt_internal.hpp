@@ -81,7 +81,7 @@ struct rt_context {
   hipStream_t sort_stream = nullptr, sort_stream_px = nullptr;   // the sort streams (eager_sort): a recorded view's tile order; its pixel list
   hipEvent_t rec_event = nullptr;      // main stream -> sort stream: "the recording frame has been enqueued up to here"
   unsigned *queue_dev = nullptr;
-  unsigned *spill_dev = nullptr;   // pooled family, twenty waves per CU, trees taller than 15 levels: the waves' box-stack overflow regions (rt_device.hpp: KParams::spill); allocated by the first launch that needs it
+  unsigned *spill_dev = nullptr;   // pooled family, twenty waves per CU, trees taller than 15 levels: the waves' box-stack overflow regions (rt_device.hpp: KParams::spill); allocated by rt_prepare_scene of such a tree (api.cpp: ensure_spill)
   size_t spill_bytes = 0;
   int *order_scratch = nullptr;   // the tile-order sort's chunk counts (rtk::kOrderScratchInts), allocated with the first record
   int *px_scratch = nullptr;      // the pixel-list sort's counts (rtk::px_scratch_ints()), likewise
